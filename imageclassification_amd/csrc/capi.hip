@@ -1,0 +1,303 @@
+// C-ABI entry points (include/icamd.h): argument checks + translation into kernel launch parameters.
+#include "../../include/icamd.h"
+#include "common.h"
+#include "icamd_internal.h"
+#include <string.h>
+
+// launchers defined in the kernel translation units
+int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream);
+int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                             float* invstd, float* scale, float* shift, double* chunks, hipStream_t s);
+int icamd_bn_eval_coeffs_launch(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                float* scale, float* shift, hipStream_t s);
+int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shift, const bf16_t* residual, bf16_t* out,
+                          long long numel, int C, int relu, hipStream_t s);
+int icamd_bn_bwd_rows_per_block(long long rows, int C);
+int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
+                        long long rows, int C, int relu, int accumulate, float* part, double* chunks, float* c1c2,
+                        hipStream_t s);
+int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
+                             hipStream_t s);
+int icamd_maxpool_bwd_launch(const bf16_t* dout, const unsigned char* idx, bf16_t* dx, int N, int IH, int IW, int C, int OH,
+                             int OW, hipStream_t s);
+int icamd_avgpool_fwd_launch(const bf16_t* x, bf16_t* out, int N, int HW, int C, hipStream_t s);
+int icamd_avgpool_bwd_launch(const bf16_t* dout, bf16_t* dx, int N, int HW, int C, hipStream_t s);
+int icamd_pack_input_launch(const float* x, bf16_t* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                            int xl, int xh, hipStream_t s);
+int icamd_softmax_xent_launch(const bf16_t* logits, int ld, int B, int C, const long long* y1, const long long* y2,
+                              float lam, float smoothing, float gscale, float* loss_rows, int* pred, bf16_t* dlogits,
+                              hipStream_t s);
+int icamd_step_metrics_launch(const float* loss_rows, const int* pred, const long long* target, int B, int C,
+                              float* loss_out, int* finite_out, double* acc_f64, int* counts, float* loss_log,
+                              int log_slot, int respect_skip, hipStream_t s);
+int icamd_grad_norm_launch(const float* g, long long n, float inv_scale, float max_norm, double* partial, float* out,
+                           hipStream_t s);
+int icamd_adamw_ema_launch(float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n, float lr,
+                           float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
+                           const float* clip, const int* finite_flag, int zero_grad, hipStream_t s);
+int icamd_lerp_launch(float* dst, const float* src, long long n, float w, const int* finite_flag, hipStream_t s);
+int icamd_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, hipStream_t s);
+int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
+                                  int njobs, hipStream_t s);
+int icamd_colsum_launch(const bf16_t* x, int rows, int ld, int cols, float* out, int accumulate, hipStream_t s);
+
+namespace {
+
+bool conv_desc_ok(const icamd_conv_desc* d) {
+  if (d == nullptr) return false;
+  if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->Cin <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0) return false;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return false;
+  if (d->KH * d->KW > ICAMD_MAX_TAPS) return false;
+  if ((d->IH + 2 * d->pad - d->KH) / d->stride + 1 != d->OH) return false;
+  if ((d->IW + 2 * d->pad - d->KW) / d->stride + 1 != d->OW) return false;
+  return true;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int icamd_abi_version(void) { return 1; }
+
+int icamd_conv2d_stats_rows(const icamd_conv_desc* d) {
+  if (!conv_desc_ok(d)) return 0;
+  const long long M = (long long)d->N * d->OH * d->OW;
+  return (int)((M + 127) / 128);
+}
+
+int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                     const void* addend, float* stats, void* stream) {
+  if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
+  if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w; p.out = (bf16_t*)y;
+  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats;
+  p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin;
+  p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
+  p.P = d->OH; p.Q = d->OW; p.M = d->N * d->OH * d->OW;
+  p.ostr = 1; p.ooff_h = 0; p.ooff_w = 0; p.istr = d->stride;
+  p.ntaps = d->KH * d->KW; p.Ktot = p.ntaps * d->Cin;
+  p.KW = d->KW; p.pad = d->pad;
+  for (int r = 0; r < d->KH; ++r)
+    for (int s = 0; s < d->KW; ++s) {
+      const int t = r * d->KW + s;
+      p.dh[t] = (short)(r - d->pad); p.dw[t] = (short)(s - d->pad); p.wtap[t] = (short)t;
+    }
+  return icamd_igemm_launch(p, (hipStream_t)stream);
+}
+
+int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
+                       void* stream) {
+  if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
+  if (d->Cout % 64 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
+  if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  const int st = d->stride;
+  // one launch per output parity class (ph, pw): pixels h = st*p + ph, w = st*q + pw receive only the taps
+  // r with (ph + pad - r) % st == 0, read at dy row p + (ph + pad - r)/st
+  for (int ph = 0; ph < st; ++ph)
+    for (int pw = 0; pw < st; ++pw) {
+      const int P = (d->IH - ph + st - 1) / st, Q = (d->IW - pw + st - 1) / st;
+      if (P <= 0 || Q <= 0) continue;
+      IgemmParams p;
+      memset(&p, 0, sizeof(p));
+      p.in = (const bf16_t*)dy; p.wt = (const bf16_t*)w_t; p.out = (bf16_t*)dx;
+      p.addend = (const bf16_t*)addend;
+      p.N = d->N; p.IH = d->OH; p.IW = d->OW; p.Cin = d->Cout;
+      p.OH = d->IH; p.OW = d->IW; p.Cout = d->Cin;
+      p.P = P; p.Q = Q; p.M = d->N * P * Q;
+      p.ostr = st; p.ooff_h = ph; p.ooff_w = pw; p.istr = 1;
+      p.Ktot = d->KH * d->KW * d->Cout;
+      p.KW = d->KW; p.pad = d->pad;
+      int nt = 0;
+      for (int r = 0; r < d->KH; ++r) {
+        const int eh = ph + d->pad - r;
+        if (((eh % st) + st) % st != 0) continue;
+        for (int s = 0; s < d->KW; ++s) {
+          const int ew = pw + d->pad - s;
+          if (((ew % st) + st) % st != 0) continue;
+          // exact division (eh, ew are multiples of st, possibly negative)
+          p.dh[nt] = (short)(eh / st); p.dw[nt] = (short)(ew / st); p.wtap[nt] = (short)(r * d->KW + s);
+          ++nt;
+        }
+      }
+      p.ntaps = nt;
+      const int rc = icamd_igemm_launch(p, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  return ICAMD_OK;
+}
+
+size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
+  if (!conv_desc_ok(d)) return 0;
+  int S = 1, rows = 0;
+  const long long M = (long long)d->N * d->OH * d->OW;
+  if (M >= (1ll << 30)) return 0;
+  const int Ktot = d->KH * d->KW * d->Cin;
+  icamd_wgrad_plan((int)M, d->Cout, Ktot, &S, &rows);
+  return (size_t)S * d->Cout * Ktot * sizeof(float);
+}
+
+int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!conv_desc_ok(d) || x == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
+  const size_t need = icamd_conv2d_wgrad_workspace_bytes(d);
+  if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.slab = (float*)workspace;
+  p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.M = d->N * d->OH * d->OW; p.Ktot = d->KH * d->KW * d->Cin;
+  icamd_wgrad_plan(p.M, p.Cout, p.Ktot, &p.S, &p.rows_per_split);
+  int rc = icamd_wgrad_launch(p, (hipStream_t)stream);
+  if (rc) return rc;
+  return icamd_slab_reduce_launch(p.slab, dw, (long long)p.Cout * p.Ktot, p.S, accumulate, (hipStream_t)stream);
+}
+
+int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
+                           void* stream) {
+  if (src_base == nullptr || dst_base == nullptr || descs == nullptr || jobs == nullptr || njobs < 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_filter_transpose_launch((const bf16_t*)src_base, (bf16_t*)dst_base, (const long long*)descs, jobs, njobs,
+                                       (hipStream_t)stream);
+}
+
+// BN workspace: [64 chunks][2][C] doubles
+size_t icamd_bn_workspace_bytes(int C) { return C > 0 ? (size_t)64 * 2 * C * sizeof(double) : 0; }
+
+int icamd_bn_train_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                            float* mean, float* invstd, float* scale, float* shift, void* workspace, void* stream) {
+  if (partials == nullptr || nrows <= 0 || C <= 0 || count <= 0 || gamma == nullptr || beta == nullptr ||
+      mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr || workspace == nullptr)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_bn_finalize_launch(partials, nrows, C, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                  invstd, scale, shift, (double*)workspace, (hipStream_t)stream);
+}
+
+int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  if (C <= 0 || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr ||
+      scale == nullptr || shift == nullptr)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_bn_eval_coeffs_launch(C, gamma, beta, running_mean, running_var, eps, scale, shift, (hipStream_t)stream);
+}
+
+int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                   long long numel, int C, int relu, void* stream) {
+  if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || numel <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)residual, (bf16_t*)out, numel, C, relu,
+                               (hipStream_t)stream);
+}
+
+// bwd workspace: partial rows [nblk][2][C] floats | chunks [64][2][C] doubles | c1,c2 [2][C] floats
+size_t icamd_bn_bwd_workspace_bytes(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const long long nblk = (rows + rpb - 1) / rpb;
+  return align_up((size_t)nblk * 2 * C * sizeof(float), 256) + align_up((size_t)64 * 2 * C * sizeof(double), 256) +
+         align_up((size_t)2 * C * sizeof(float), 256);
+}
+
+int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
+                 const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
+                 long long rows, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (dout == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr ||
+      dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 || C <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  const size_t need = icamd_bn_bwd_workspace_bytes(rows, C);
+  if (workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const long long nblk = (rows + rpb - 1) / rpb;
+  char* ws = (char*)workspace;
+  float* part = (float*)ws;
+  ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
+  double* chunks = (double*)ws;
+  ws += align_up((size_t)64 * 2 * C * sizeof(double), 256);
+  float* c1c2 = (float*)ws;
+  return icamd_bn_bwd_launch((const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, mean, invstd, scale, shift, dgamma,
+                             dbeta, (bf16_t*)dy, (bf16_t*)gout, rows, C, relu, accumulate, part, chunks, c1c2,
+                             (hipStream_t)stream);
+}
+
+int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {
+  if (x == nullptr || out == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
+  return icamd_maxpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, argmax, N, IH, IW, C, OH, OW, (hipStream_t)stream);
+}
+
+int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream) {
+  if (dout == nullptr || argmax == nullptr || dx == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
+  return icamd_maxpool_bwd_launch((const bf16_t*)dout, argmax, (bf16_t*)dx, N, IH, IW, C, OH, OW, (hipStream_t)stream);
+}
+
+int icamd_avgpool_fwd(const void* x, void* out, int N, int HW, int C, void* stream) {
+  if (x == nullptr || out == nullptr || N <= 0 || HW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_avgpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, N, HW, C, (hipStream_t)stream);
+}
+
+int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* stream) {
+  if (dout == nullptr || dx == nullptr || N <= 0 || HW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_avgpool_bwd_launch((const bf16_t*)dout, (bf16_t*)dx, N, HW, C, (hipStream_t)stream);
+}
+
+int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                     int xl, int xh, void* stream) {
+  if (x == nullptr || out == nullptr || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return ICAMD_ERR_BAD_ARG;
+  if (mode != 0 && (B % 2) != 0) return ICAMD_ERR_BAD_ARG;  // timm Mixup asserts an even batch
+  return icamd_pack_input_launch(x, (bf16_t*)out, B, Cin, H, W, mode, lam, yl, yh, xl, xh, (hipStream_t)stream);
+}
+
+int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* y1, const int64_t* y2, float lam,
+                       float smoothing, float gscale, float* loss_rows, int32_t* pred, void* dlogits, void* stream) {
+  if (logits == nullptr || y1 == nullptr || loss_rows == nullptr) return ICAMD_ERR_BAD_ARG;
+  return icamd_softmax_xent_launch((const bf16_t*)logits, ld, B, C, (const long long*)y1, (const long long*)y2, lam,
+                                   smoothing, gscale, loss_rows, pred, (bf16_t*)dlogits, (hipStream_t)stream);
+}
+
+int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_t* target, int B, int C,
+                       float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
+                       int log_slot, int respect_skip, void* stream) {
+  if (loss_rows == nullptr || loss_out == nullptr || finite_out == nullptr || acc_f64 == nullptr || B <= 0) return ICAMD_ERR_BAD_ARG;
+  if (pred != nullptr && target == nullptr) return ICAMD_ERR_BAD_ARG;
+  return icamd_step_metrics_launch(loss_rows, pred, (const long long*)target, B, C, loss_out, finite_out, acc_f64, counts,
+                                   loss_log, log_slot, respect_skip, (hipStream_t)stream);
+}
+
+size_t icamd_grad_norm_workspace_bytes(void) { return 512 * sizeof(double); }
+
+int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm, void* workspace, float* out,
+                    void* stream) {
+  if (g == nullptr || n <= 0 || workspace == nullptr || out == nullptr) return ICAMD_ERR_BAD_ARG;
+  return icamd_grad_norm_launch(g, n, inv_scale, max_norm, (double*)workspace, out, (hipStream_t)stream);
+}
+
+int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
+                    float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
+                    const int32_t* finite_flag, int zero_grad, void* stream) {
+  if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_adamw_ema_launch(p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
+                                clip, finite_flag, zero_grad, (hipStream_t)stream);
+}
+
+int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream) {
+  if (dst == nullptr || src == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_lerp_launch(dst, src, n, w, finite_flag, (hipStream_t)stream);
+}
+
+int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
+  if (src == nullptr || dst == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_f32_to_bf16_launch(src, (bf16_t*)dst, n, (hipStream_t)stream);
+}
+
+int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream) {
+  if (x == nullptr || out == nullptr || rows <= 0 || cols <= 0 || ld < cols) return ICAMD_ERR_BAD_ARG;
+  return icamd_colsum_launch((const bf16_t*)x, rows, ld, cols, out, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the training-step hot path.
+// Wave = 64 lanes everywhere; bf16 values travel as raw 16-bit patterns (unsigned short).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ICAMD_OK 0
+#define ICAMD_ERR_BAD_ARG 1
+#define ICAMD_ERR_UNSUPPORTED 2
+#define ICAMD_ERR_WORKSPACE 3
+#define ICAMD_ERR_LAUNCH 4
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
+#define LPTR(p) ((void __attribute__((address_space(3)))*)(p))
+
+// 256 B of zeros in device memory: the source of every out-of-image / out-of-range LDS-DMA lane.
+// (one zero-initialised copy per translation unit: no relocatable device code needed)
+static __device__ __attribute__((aligned(256))) unsigned int icamd_zero_page[64];
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((unsigned int)v) << 16);
+}
+// Round-to-nearest-even f32 -> bf16 through the hardware convert (keeps NaN a NaN).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Exact unsigned division by a runtime constant (n < 2^31, d >= 1): q = (n * mul) >> 32 >> sh.
+struct FastDiv {
+  unsigned int mul, sh, d, pad;
+};
+__device__ __forceinline__ unsigned int fdiv(unsigned int n, const FastDiv& f) {
+  return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.sh);
+}
+static inline FastDiv make_fastdiv(unsigned int d) {
+  FastDiv f; f.d = d; f.pad = 0;
+  if (d == 1) { f.mul = 0; f.sh = 0; return f; }
+  unsigned int l = 0; while ((1ull << l) < d) ++l;          // ceil(log2 d)
+  unsigned long long m = ((1ull << (32 + l - 1)) + d - 1) / d;  // round-up magic for n < 2^31
+  f.mul = (unsigned int)m; f.sh = l - 1;
+  return f;
+}
+
+static inline int icamd_launch_status() {
+  return hipGetLastError() == hipSuccess ? ICAMD_OK : ICAMD_ERR_LAUNCH;
+}

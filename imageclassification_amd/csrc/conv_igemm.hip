@@ -1,0 +1,279 @@
+// Implicit-GEMM convolution for gfx950: NHWC bf16 activations, [Cout][taps][Cin] bf16 filters,
+// fp32 MFMA accumulation (v_mfma_f32_16x16x32_bf16), one kernel for forward and data-gradient.
+//
+// Replaces what ATen dispatches for `model(samples)` / `loss.backward()` in the reference's step
+// (/root/reference/engine.py:48,51,64,72 through timm's conv layers, train.py:194).
+//
+// GEMM view: out[m][co] = sum_k A[m][k] * W[co][k], m = (n,p,q) output pixel, k = (tap, ci).
+//   * A rows are gathered straight from the NHWC tensor into LDS by LDS-DMA (global_load_lds, 16 B per
+//     lane, per-lane source address = the gather); out-of-image taps read a 256 B zero page.
+//   * LDS tiles are [row][64 k] bf16 (128 B rows); the 16 B chunk index is XOR-swizzled with (row>>1)&7 on
+//     the SOURCE address (LDS destination stays lane-linear) and on the ds_read_b128 fragment reads.
+//   * MFMA operands are swapped (A-operand = filter rows, B-operand = pixel rows) so each lane ends with 4
+//     consecutive output channels of one pixel; the tile is transposed through LDS in fp32 and leaves as
+//     whole 16 B / 256 B-coalesced bf16 rows, rounded exactly once after bias / addend are added in fp32.
+//   * Optional epilogue: per-channel sum and sum-of-squares of the ROUNDED outputs (BatchNorm batch
+//     statistics), written as one deterministic partial row per m-tile (no float atomics).
+// The same kernel runs the data gradient: "input" = dY, filters = the [Cin][taps][Cout] transposed copy,
+// taps negated; stride-2 gradients run as 4 parity classes (ostr=2, only the taps that hit each class).
+#include "common.h"
+#include "icamd_internal.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+template <int BN, bool CIN8>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
+  constexpr int A_BYTES = BM * BK * 2;
+  constexpr int B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int EPI_BYTES = BM * BN * 4;
+  constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+  constexpr int NJ = BN / 32;   // filter-row fragments per wave (wave covers BN/2 channels)
+  constexpr int BROWS = BN / 32;  // B staging instructions per wave
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of tiles,
+  // n-tiles of one m-tile adjacent, so the gathered A rows are fetched from HBM once per XCD.
+  const unsigned int nblk = gridDim.x;
+  unsigned int L;
+  {
+    const unsigned int xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned int q = nblk >> 3, r = nblk & 7u;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int ntn = p.ntiles_n;
+  const int tile_m = L / ntn, tile_n = L - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ in = p.in;
+  const bf16_t* __restrict__ wt = p.wt;
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+
+  // ---- per-lane gather state for the 4 A rows this lane stages ----
+  int a_base[4], a_ih0[4], a_iw0[4], a_lc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wave * 32 + j * 8 + (lane >> 3);
+    const int m = m0 + row;
+    a_lc[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // logical k offset (elements) of this lane's chunk
+    if (m < p.M) {
+      const unsigned int n = fdiv((unsigned)m, p.divPQ);
+      const unsigned int rem = m - n * (p.P * p.Q);
+      const unsigned int pp = fdiv(rem, p.divQ);
+      const unsigned int qq = rem - pp * p.Q;
+      a_ih0[j] = pp * p.istr;
+      a_iw0[j] = qq * p.istr;
+      a_base[j] = ((n * p.IH + a_ih0[j]) * p.IW + a_iw0[j]) * p.Cin;
+    } else {
+      a_ih0[j] = -(1 << 20);
+      a_iw0[j] = -(1 << 20);
+      a_base[j] = 0;
+    }
+  }
+  int b_off[BROWS];  // element offset of this lane's filter row (+ its swizzled chunk), or -1
+#pragma unroll
+  for (int j = 0; j < BROWS; ++j) {
+    const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
+    const int co = n0 + row;
+    const int lc = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    b_off[j] = (co < p.Cout) ? co * p.Ktot + lc : -1;
+  }
+
+  auto stage = [&](int ks, int buf) {
+    unsigned char* sA = smem + buf * STAGE_BYTES;
+    unsigned char* sB = sA + A_BYTES;
+    if constexpr (!CIN8) {
+      // all 64 k of this step share one tap (Cin % 64 == 0): tap index and channel offset are wave-uniform
+      const int kk0 = ks * BK;
+      const int t = kk0 / p.Cin;          // uniform
+      const int ci0 = kk0 - t * p.Cin;
+      const int dh = p.dh[t], dw = p.dw[t];
+      const int tapoff = (dh * p.IW + dw) * p.Cin + ci0;
+      const int woff = p.wtap[t] * p.Cin + ci0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+        const bool ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
+        const bf16_t* src = ok ? in + (a_base[j] + tapoff + a_lc[j]) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * 32 + j * 8) * 128), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const bf16_t* src = (b_off[j] >= 0) ? wt + (b_off[j] + woff) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
+      }
+    } else {
+      // Cin == 8 (padded stem): every 16 B chunk is its own tap; taps follow the regular (r,s) rule
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = ks * 8 + (a_lc[j] >> 3);
+        const int r = t / p.KW, s = t - r * p.KW;
+        const int dh = r - p.pad, dw = s - p.pad;
+        const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
+        const bool ok = (t < p.ntaps) && ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
+        const bf16_t* src = ok ? in + (a_base[j] + (dh * p.IW + dw) * 8) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * 32 + j * 8) * 128), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
+        const int lc = ((lane & 7) ^ ((row >> 1) & 7));
+        const int t = ks * 8 + lc;
+        // b_off already holds co*Ktot + lc*8; the step adds ks*64
+        const bf16_t* src = (b_off[j] >= 0 && t < p.ntaps) ? wt + (b_off[j] + ks * BK) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = fr >> 1;  // (row>>1)&7 for every fragment row this lane reads (rows are 16-aligned + fr)
+
+  const int nks = p.ksteps;
+  if (nks > 0) stage(0, 0);
+  __syncthreads();  // emits vmcnt(0): stage 0 has landed
+  for (int ks = 0; ks < nks; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+    const unsigned char* sA = smem + buf * STAGE_BYTES;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = ((kk * 4 + fq) ^ sw) * 16;
+      bf16x8 xf[4], wf[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xf[i] = *(const bf16x8*)(sA + (wm * 64 + i * 16 + fr) * 128 + chunk);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        wf[j] = *(const bf16x8*)(sB + (wn * (BN / 2) + j * 16 + fr) * 128 + chunk);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading this buffer
+  }
+
+  // ---- epilogue: accumulators -> fp32 LDS tile [m][co] (16 B chunks XOR-swizzled by m&7) ----
+  constexpr int ROWB = BN * 4;  // bytes per fp32 tile row
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ml = wm * 64 + i * 16 + fr;
+      const int c16 = (wn * (BN / 2) + j * 16 + 4 * fq) >> 2;
+      *(f32x4*)(smem + ml * ROWB + ((c16 ^ (ml & 7)) << 4)) = acc[j][i];
+    }
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;          // 8-channel groups per row
+  constexpr int RPP = 256 / CPR;       // rows per pass
+  constexpr int NPASS = BM / RPP;
+  const int cp = tid % CPR, rg = tid / CPR;
+  const int co = n0 + cp * 8;
+  const bool co_ok = co < p.Cout;  // Cout % 8 == 0 (host-checked)
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = (p.bias != nullptr && co_ok) ? p.bias[co + e] : 0.f;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int ml = ps * RPP + rg;
+    const int m = m0 + ml;
+    const f32x4 v0 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp) ^ (ml & 7)) << 4));
+    const f32x4 v1 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp + 1) ^ (ml & 7)) << 4));
+    if (m < p.M && co_ok) {
+      const unsigned int n = fdiv((unsigned)m, p.divPQ);
+      const unsigned int rem = m - n * (p.P * p.Q);
+      const unsigned int pp = fdiv(rem, p.divQ);
+      const unsigned int qq = rem - pp * p.Q;
+      const long long pix = ((long long)n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w;
+      const long long off = pix * p.Cout + co;
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+      if (p.addend != nullptr) {
+        const u32x4 a = *(const u32x4*)(p.addend + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(a[e]); v[2 * e + 1] += bf16_hi(a[e]); }
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      *(u32x4*)(p.out + off) = o;
+      if (p.stats != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf16_lo(o[e]), hi = bf16_hi(o[e]);
+          s1[2 * e] += lo; s2[2 * e] += lo * lo;
+          s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+        }
+      }
+    }
+  }
+
+  if (p.stats != nullptr) {
+    __syncthreads();  // all tile reads done; reuse LDS for the cross-row-group reduction
+    float* red = (float*)smem;  // [RPP][2][BN]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(rg * 2 + 0) * BN + cp * 8 + e] = s1[e];
+      red[(rg * 2 + 1) * BN + cp * 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid - which * BN;
+      float s = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + c];
+      if (n0 + c < p.Cout) p.stats[((long long)tile_m * 2 + which) * p.Cout + n0 + c] = s;
+    }
+  }
+}
+
+template <int BN, bool CIN8>
+int launch(const IgemmParams& p, hipStream_t stream) {
+  const int ntm = (p.M + BM - 1) / BM;
+  dim3 grid((unsigned)(ntm * p.ntiles_n));
+  hipLaunchKernelGGL((conv_igemm_kernel<BN, CIN8>), grid, dim3(256), 0, stream, p);
+  return icamd_launch_status();
+}
+
+}  // namespace
+
+int icamd_igemm_pick_bn(int Cout) { return Cout <= 64 ? 64 : 128; }
+
+int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
+  if (p.Cout % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
+  const bool cin8 = (p.Cin == 8);
+  if (!cin8 && (p.Cin % 64 != 0)) return ICAMD_ERR_UNSUPPORTED;
+  if ((long long)p.N * p.IH * p.IW * p.Cin >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  if ((long long)p.Cout * p.Ktot >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  if (p.M <= 0 || p.ntaps < 0 || p.ntaps > ICAMD_MAX_TAPS) return ICAMD_ERR_BAD_ARG;
+  const int bn = icamd_igemm_pick_bn(p.Cout);
+  p.ntiles_n = (p.Cout + bn - 1) / bn;
+  p.ksteps = (p.ntaps * p.Cin + BK - 1) / BK;
+  p.divPQ = make_fastdiv((unsigned)(p.P * p.Q));
+  p.divQ = make_fastdiv((unsigned)p.Q);
+  if (bn == 64) return cin8 ? launch<64, true>(p, stream) : launch<64, false>(p, stream);
+  return cin8 ? launch<128, true>(p, stream) : launch<128, false>(p, stream);
+}

@@ -1,0 +1,42 @@
+// Internal launch-parameter blocks shared between the C-ABI layer (capi.hip) and the kernels.
+#pragma once
+#include "common.h"
+
+#define ICAMD_MAX_TAPS 56
+
+// One implicit-GEMM problem: out[n, p*ostr+ooff_h, q*ostr+ooff_w, :] = sum over active taps t, ci of
+//   in[n, p*istr+dh[t], q*istr+dw[t], ci] * wt[co][wtap[t]][ci]        (+ bias[co] + addend[same pixel])
+struct IgemmParams {
+  const bf16_t* in;
+  const bf16_t* wt;
+  bf16_t* out;
+  const bf16_t* addend;  // optional, laid out like out
+  const float* bias;     // optional [Cout]
+  float* stats;          // optional [ceil(M/128)][2][Cout] partial sum / sum-of-squares of rounded outputs
+  int N, IH, IW, Cin;
+  int OH, OW, Cout;
+  int P, Q, M;           // output sub-grid and row count N*P*Q
+  int ostr, ooff_h, ooff_w, istr;
+  int ntaps, Ktot;       // active taps; filter row length (elements)
+  int KW, pad;           // regular-tap rule for the Cin==8 stem path
+  int ksteps, ntiles_n;  // filled by the launcher
+  FastDiv divPQ, divQ;   // filled by the launcher
+  short dh[ICAMD_MAX_TAPS], dw[ICAMD_MAX_TAPS], wtap[ICAMD_MAX_TAPS];
+};
+int icamd_igemm_launch(IgemmParams& p, hipStream_t stream);
+int icamd_igemm_pick_bn(int Cout);
+
+// Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
+struct WgradParams {
+  const bf16_t* x;    // [N, IH, IW, Cin]
+  const bf16_t* dy;   // [N, OH, OW, Cout]
+  float* slab;        // [S][Cout][Ktot] partial sums
+  int N, IH, IW, Cin, OH, OW, Cout;
+  int KH, KW, stride, pad;
+  int M, Ktot;        // N*OH*OW ; KH*KW*Cin
+  int S, rows_per_split;  // split of the m reduction
+  int ntiles_k, ntiles_c;
+  FastDiv divHW, divW, divCin, divKW;
+};
+int icamd_wgrad_launch(WgradParams& p, hipStream_t stream);
+void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split);

@@ -1,0 +1,573 @@
+// HBM-bound kernels of the ResNet step for gfx950: BatchNorm (training statistics, apply, backward),
+// ReLU / residual add fused into the BN apply, 3x3/s2 max-pool, global average pool, input packing.
+// All activations are NHWC bf16 moved as 16 B (8-channel) vectors; statistics are fp32 per thread,
+// fp64 across workgroups, combined in a fixed order (bitwise reproducible, no float atomics).
+//
+// Replaces what ATen runs for timm's BatchNorm2d / ReLU / MaxPool2d / pooling layers under
+// `model(samples)` and `loss.backward()` in /root/reference/engine.py:48,51,64,72.
+#include "common.h"
+#include "icamd_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Two-level per-channel reduction of partial rows:  part[nrows][2][C] (fp32) -> out[nchunks][2][C] (fp64)
+// grid = (ceil(C/64), nchunks); block 256 = 64 channels x 4 row lanes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, double* __restrict__ out,
+                                                             int nrows, int C, int rows_per_chunk) {
+  __shared__ double red[4][2][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(nrows, r0 + rows_per_chunk);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int r = r0 + rl; r < r1; r += 4) {
+      s1 += (double)part[((long long)r * 2 + 0) * C + c];
+      s2 += (double)part[((long long)r * 2 + 1) * C + c];
+    }
+  }
+  red[rl][0][threadIdx.x & 63] = s1;
+  red[rl][1][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+    const double s = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+    const int co = blockIdx.x * 64 + cc;
+    if (co < C) out[((long long)blockIdx.y * 2 + which) * C + co] = s;
+  }
+}
+
+// BatchNorm training-mode finalize (torch.nn.functional.batch_norm semantics: biased variance for the
+// normalisation, unbiased for the running estimate, running = (1-mom)*running + mom*batch).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part2, int nchunks, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float momentum, float eps,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                          float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nchunks; ++k) {
+    s1 += part2[((long long)k * 2 + 0) * C + c];
+    s2 += part2[((long long)k * 2 + 1) * C + c];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  mean_out[c] = meanf;
+  invstd_out[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - meanf * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval-mode BN: scale/shift from the running estimates
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - running_mean[c] * sc;
+}
+
+// out = act(y*scale[c] + shift[c] (+ residual)); 8 channels per thread
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const bf16_t* __restrict__ residual,
+                                                       bf16_t* __restrict__ out, long long nvec, int cpr, int relu) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // the launcher makes stride a multiple of cpr, so this thread's channel group never changes
+  const int cg = (int)(i % cpr) * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[cg + e]; sh[e] = shift[cg + e]; }
+  for (; i < nvec; i += stride) {
+    const u32x4 v = ((const u32x4*)y)[i];
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = fmaf(bf16_lo(v[e]), sc[2 * e], sh[2 * e]);
+      f[2 * e + 1] = fmaf(bf16_hi(v[e]), sc[2 * e + 1], sh[2 * e + 1]);
+    }
+    if (residual != nullptr) {
+      const u32x4 r = ((const u32x4*)residual)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[2 * e] += bf16_lo(r[e]); f[2 * e + 1] += bf16_hi(r[e]); }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+    ((u32x4*)out)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN backward, pass 1: per-channel partial sums of g and g*xhat, g = dout * [act > 0]
+//   act == nullptr && relu : mask recomputed from y*scale+shift > 0 (no residual in front of the ReLU)
+// rows are pixels; block handles `rows_per_block` rows; part[blk][2][C]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act,
+                                                            const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ part,
+                                                            long long rows, int C, int rows_per_block, int relu) {
+  __shared__ float red[256 * 16];
+  const int cpr = C >> 3;                 // 8-channel groups per row
+  const int tid = threadIdx.x;
+  // thread -> (channel group, row lane); when cpr > 256 the block loops over channel-group tiles
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = (rows < r0 + rows_per_block) ? rows : r0 + rows_per_block;
+  for (int cg0 = 0; cg0 < cpr; cg0 += 256) {
+    const int tcols = (cpr - cg0 < 256) ? (cpr - cg0) : 256;   // channel groups in this tile
+    const int rlanes = 256 / tcols;                              // row lanes
+    const int cgi = tid % tcols, rl = tid / tcols;
+    float sg[8], sgx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sgx[e] = 0.f; }
+    if (rl < rlanes) {
+      const int c = (cg0 + cgi) * 8;
+      float mu[8], is[8], sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+      for (long long r = r0 + rl; r < r1; r += rlanes) {
+        const long long off = r * cpr + cg0 + cgi;
+        const u32x4 d = ((const u32x4*)dout)[off];
+        const u32x4 yv = ((const u32x4*)y)[off];
+        float g[8], yy[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[2 * e] = bf16_lo(d[e]); g[2 * e + 1] = bf16_hi(d[e]);
+          yy[2 * e] = bf16_lo(yv[e]); yy[2 * e + 1] = bf16_hi(yv[e]);
+        }
+        if (relu) {
+          if (act != nullptr) {
+            const u32x4 a = ((const u32x4*)act)[off];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (!(bf16_lo(a[e]) > 0.f)) g[2 * e] = 0.f;
+              if (!(bf16_hi(a[e]) > 0.f)) g[2 * e + 1] = 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (!(fmaf(yy[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sg[e] += g[e];
+          sgx[e] += g[e] * ((yy[e] - mu[e]) * is[e]);
+        }
+      }
+    }
+    // cross-row-lane reduction through LDS: red[tid][16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = sg[e]; red[tid * 16 + 8 + e] = sgx[e]; }
+    __syncthreads();
+    // tcols*16 outputs; thread t sums over row lanes
+    for (int o = tid; o < tcols * 16; o += 256) {
+      const int cgo = o >> 4, e = o & 15;
+      float s = 0.f;
+      for (int l = 0; l < rlanes; ++l) s += red[(l * tcols + cgo) * 16 + e];
+      const int which = e >> 3;
+      part[((long long)blockIdx.x * 2 + which) * C + (cg0 + cgo) * 8 + (e & 7)] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// BN backward finalize: dgamma = sum g*xhat, dbeta = sum g; coefficients for pass 2
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part2, int nchunks, int C,
+                                                              double count, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ c1_out,
+                                                              float* __restrict__ c2_out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int k = 0; k < nchunks; ++k) {
+    sg += part2[((long long)k * 2 + 0) * C + c];
+    sgx += part2[((long long)k * 2 + 1) * C + c];
+  }
+  c1_out[c] = (float)(sg / count);
+  c2_out[c] = (float)(sgx / count);
+  if (accumulate) { dgamma[c] += (float)sgx; dbeta[c] += (float)sg; }
+  else { dgamma[c] = (float)sgx; dbeta[c] = (float)sg; }
+}
+
+// BN backward, pass 2: dy = scale * (g - c1 - xhat*c2); optionally also stores g (masked dout) in gout
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ act,
+                                                           const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ c1,
+                                                           const float* __restrict__ c2, bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ gout, long long nvec, int cpr, int relu) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(i % cpr) * 8;
+  float mu[8], is[8], sc[8], sh[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[cg + e]; is[e] = invstd[cg + e]; sc[e] = scale[cg + e]; sh[e] = shift[cg + e];
+    k1[e] = c1[cg + e]; k2[e] = c2[cg + e];
+  }
+  for (; i < nvec; i += stride) {
+    const u32x4 d = ((const u32x4*)dout)[i];
+    const u32x4 yv = ((const u32x4*)y)[i];
+    float g[8], yy[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g[2 * e] = bf16_lo(d[e]); g[2 * e + 1] = bf16_hi(d[e]);
+      yy[2 * e] = bf16_lo(yv[e]); yy[2 * e + 1] = bf16_hi(yv[e]);
+    }
+    if (relu) {
+      if (act != nullptr) {
+        const u32x4 a = ((const u32x4*)act)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!(bf16_lo(a[e]) > 0.f)) g[2 * e] = 0.f;
+          if (!(bf16_hi(a[e]) > 0.f)) g[2 * e + 1] = 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!(fmaf(yy[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
+      }
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = sc[e] * (g[e] - k1[e] - ((yy[e] - mu[e]) * is[e]) * k2[e]);
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+    ((u32x4*)dy)[i] = ov;
+    if (gout != nullptr) {
+      u32x4 gv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = pack_bf16x2(g[2 * e], g[2 * e + 1]);
+      ((u32x4*)gout)[i] = gv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool 3x3 stride 2 pad 1 (torch scan order: rows then columns, first maximum wins, NaN propagates)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                               unsigned char* __restrict__ idx, int N, int IH, int IW,
+                                                               int C, int OH, int OW) {
+  const int cpr = C >> 3;
+  const long long total = (long long)N * OH * OW * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cg = (int)(i % cpr);
+    long long t = i / cpr;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = oh * 2 - 1 + r;
+      if ((unsigned)ih >= (unsigned)IH) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iw = ow * 2 - 1 + s;
+        if ((unsigned)iw >= (unsigned)IW) continue;
+        const u32x4 v = ((const u32x4*)x)[((long long)(n * IH + ih) * IW + iw) * cpr + cg];
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(v[e]); f[2 * e + 1] = bf16_hi(v[e]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (first || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = r * 3 + s; }
+        }
+        first = false;
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(best[2 * e], best[2 * e + 1]);
+    ((u32x4*)out)[i] = o;
+    if (idx != nullptr) {
+      u32x2 iv;
+      iv[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      iv[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      ((u32x2*)idx)[i] = iv;
+    }
+  }
+}
+
+// dx[n,h,w,c] = sum over the (<=4) windows that cover (h,w) and whose recorded argmax is (h,w)
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ dout,
+                                                               const unsigned char* __restrict__ idx,
+                                                               bf16_t* __restrict__ dx, int N, int IH, int IW, int C,
+                                                               int OH, int OW) {
+  const int cpr = C >> 3;
+  const long long total = (long long)N * IH * IW * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cg = (int)(i % cpr);
+    long long t = i / cpr;
+    const int w = (int)(t % IW); t /= IW;
+    const int h = (int)(t % IH);
+    const int n = (int)(t / IH);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1;   // windows rows covering h: ceil((h-1)/2) .. floor((h+1)/2)
+    const int ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      if (oh >= OH) continue;
+      const int r = h - (oh * 2 - 1);
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        if (ow >= OW) continue;
+        const int s = w - (ow * 2 - 1);
+        const int code = r * 3 + s;
+        const long long o = ((long long)(n * OH + oh) * OW + ow) * cpr + cg;
+        const u32x2 iv = ((const u32x2*)idx)[o];
+        const u32x4 d = ((const u32x4*)dout)[o];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int code_e = (iv[e >> 2] >> ((e & 3) * 8)) & 0xff;
+          const float dv = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
+          if (code_e == code) acc[e] += dv;
+        }
+      }
+    }
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
+    ((u32x4*)dx)[i] = ov;
+  }
+}
+
+// global average pool: x[N][HW][C] -> out[N][C] (fp32 mean rounded once to bf16)
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                          int N, int HW, int C) {
+  const int cpr = C >> 3;
+  const long long total = (long long)N * cpr;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % cpr);
+  const int n = (int)(i / cpr);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int p = 0; p < HW; ++p) {
+    const u32x4 v = ((const u32x4*)x)[((long long)n * HW + p) * cpr + cg];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += bf16_lo(v[e]); acc[2 * e + 1] += bf16_hi(v[e]); }
+  }
+  const float inv = 1.0f / (float)HW;
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e] * inv, acc[2 * e + 1] * inv);
+  ((u32x4*)out)[i] = o;
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ dx,
+                                                          int N, int HW, int C) {
+  const int cpr = C >> 3;
+  const long long total = (long long)N * HW * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float inv = 1.0f / (float)HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cg = (int)(i % cpr);
+    const int n = (int)(i / ((long long)HW * cpr));
+    const u32x4 d = ((const u32x4*)dout)[(long long)n * cpr + cg];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16_lo(d[e]) * inv, bf16_hi(d[e]) * inv);
+    ((u32x4*)dx)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input packing: NCHW fp32 [B,3,H,W] -> NHWC bf16 [B,H,W,8] (channels 3..7 zero), with the batch-mode
+// mixup / cutmix of timm.data.Mixup fused in (x <- lam*x + (1-lam)*x.flip(0), or a pasted box):
+// the mix is done in fp32 on the fp32 pixels, then rounded once. mode 0 none, 1 mixup, 2 cutmix.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B,
+                                                         int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                                                         int xl, int xh) {
+  const long long total = (long long)B * H * W;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long hw = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int b = (int)(i / hw);
+    const long long pix = i - (long long)b * hw;
+    const int h = (int)(pix / W), w = (int)(pix - (long long)h * W);
+    float f[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = 0.f;
+    const int fb = B - 1 - b;
+    for (int c = 0; c < Cin; ++c) {
+      float v = x[((long long)b * Cin + c) * hw + pix];
+      if (mode == 1) {
+        const float o = x[((long long)fb * Cin + c) * hw + pix];
+        v = v * lam + o * (1.f - lam);
+      } else if (mode == 2) {
+        if (h >= yl && h < yh && w >= xl && w < xh) v = x[((long long)fb * Cin + c) * hw + pix];
+      }
+      f[c] = v;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+    ((u32x4*)out)[i] = o;
+  }
+}
+
+inline unsigned int grid_for(long long work_items, int threads, int multiple_of) {
+  long long blocks = (work_items + threads - 1) / threads;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (multiple_of > 1) blocks = (blocks + multiple_of - 1) / multiple_of * multiple_of;
+  return (unsigned int)blocks;
+}
+inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+}  // namespace
+
+// ---------------- host launchers (called from capi.hip) ----------------
+
+int icamd_partials_to_chunks(const float* part, int nrows, int C, double* chunks, int* nchunks_out, hipStream_t s) {
+  // chunk so that each block walks <= 64*4 rows; at most 64 chunks
+  int rows_per_chunk = 256;
+  int nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk;
+  if (nchunks > 64) { nchunks = 64; rows_per_chunk = (nrows + 63) / 64; nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk; }
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)nchunks);
+  hipLaunchKernelGGL(partial_reduce_kernel, grid, dim3(256), 0, s, part, chunks, nrows, C, rows_per_chunk);
+  *nchunks_out = nchunks;
+  return icamd_launch_status();
+}
+
+int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                             float* invstd, float* scale, float* shift, double* chunks, hipStream_t s) {
+  int nchunks = 0;
+  int rc = icamd_partials_to_chunks(part, nrows, C, chunks, &nchunks, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, chunks, nchunks, C, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  return icamd_launch_status();
+}
+
+int icamd_bn_eval_coeffs_launch(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, C, gamma, beta, rm, rv,
+                     eps, scale, shift);
+  return icamd_launch_status();
+}
+
+static unsigned int elementwise_grid(long long nvec, int cpr) {
+  // total threads must be a multiple of cpr so a thread's channel group is loop-invariant
+  const int mult = cpr / gcd_i(cpr, 256);
+  return grid_for(nvec, 256, mult);
+}
+
+int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shift, const bf16_t* residual, bf16_t* out,
+                          long long numel, int C, int relu, hipStream_t s) {
+  if (C % 8 != 0 || numel % C != 0) return ICAMD_ERR_BAD_ARG;
+  const long long nvec = numel / 8;
+  const int cpr = C / 8;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(elementwise_grid(nvec, cpr)), dim3(256), 0, s, y, scale, shift, residual, out,
+                     nvec, cpr, relu);
+  return icamd_launch_status();
+}
+
+int icamd_bn_bwd_rows_per_block(long long rows, int C) {
+  // aim for ~2048 blocks, at least 32 rows each
+  long long rpb = (rows + 2047) / 2048;
+  if (rpb < 32) rpb = 32;
+  (void)C;
+  return (int)rpb;
+}
+
+int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
+                        long long rows, int C, int relu, int accumulate, float* part, double* chunks, float* c1c2,
+                        hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const int nblk = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dout, act, y, mean, invstd, scale, shift,
+                     part, rows, C, rpb, relu);
+  int rc = icamd_launch_status();
+  if (rc) return rc;
+  int nchunks = 0;
+  rc = icamd_partials_to_chunks(part, nblk, C, chunks, &nchunks, s);
+  if (rc) return rc;
+  float* c1 = c1c2;
+  float* c2 = c1c2 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, chunks, nchunks, C,
+                     (double)rows, dgamma, dbeta, c1, c2, accumulate);
+  rc = icamd_launch_status();
+  if (rc) return rc;
+  const long long nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, act, y, mean, invstd,
+                     scale, shift, c1, c2, dy, gout, nvec, C / 8, relu);
+  return icamd_launch_status();
+}
+
+int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
+                             hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)N * OH * OW * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, x, out, idx, N, IH, IW, C,
+                     OH, OW);
+  return icamd_launch_status();
+}
+
+int icamd_maxpool_bwd_launch(const bf16_t* dout, const unsigned char* idx, bf16_t* dx, int N, int IH, int IW, int C, int OH,
+                             int OW, hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)N * IH * IW * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, dout, idx, dx, N, IH, IW,
+                     C, OH, OW);
+  return icamd_launch_status();
+}
+
+int icamd_avgpool_fwd_launch(const bf16_t* x, bf16_t* out, int N, int HW, int C, hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)N * (C / 8);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, N, HW, C);
+  return icamd_launch_status();
+}
+
+int icamd_avgpool_bwd_launch(const bf16_t* dout, bf16_t* dx, int N, int HW, int C, hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)N * HW * (C / 8);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for(total, 256, 1)), dim3(256), 0, s, dout, dx, N, HW, C);
+  return icamd_launch_status();
+}
+
+int icamd_pack_input_launch(const float* x, bf16_t* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                            int xl, int xh, hipStream_t s) {
+  if (Cin < 1 || Cin > 8) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)B * H * W;
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(total, 256, 1) * 2), dim3(256), 0, s, x, out, B, Cin, H, W, mode, lam,
+                     yl, yh, xl, xh);
+  return icamd_launch_status();
+}

@@ -1,0 +1,108 @@
+"""ctypes binding of libicamd.so (include/icamd.h) -- the only way the package reaches the GPU kernels.
+
+There is no CPU or PyTorch fallback: if the shared library is missing or a symbol is absent, import of the
+compute path raises.  PyTorch is used for device memory (tensors), streams and torch.distributed only.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libicamd.so")
+
+ERRORS = {1: "ICAMD_ERR_BAD_ARG", 2: "ICAMD_ERR_UNSUPPORTED", 3: "ICAMD_ERR_WORKSPACE", 4: "ICAMD_ERR_LAUNCH"}
+
+
+class IcamdError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in ("N", "IH", "IW", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad")]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+def conv_desc(N, IH, IW, Cin, Cout, KH, KW, stride, pad):
+    OH = (IH + 2 * pad - KH) // stride + 1
+    OW = (IW + 2 * pad - KW) // stride + 1
+    return ConvDesc(N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad)
+
+
+# name -> (restype, argtypes); mirrors include/icamd.h one to one
+_P = c_void_p
+_SIGNATURES = {
+    "icamd_abi_version": (c_int, []),
+    "icamd_conv2d_stats_rows": (c_int, [POINTER(ConvDesc)]),
+    "icamd_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "icamd_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "icamd_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "icamd_filter_transpose": (c_int, [_P, _P, _P, _P, c_int, _P]),
+    "icamd_bn_workspace_bytes": (c_size_t, [c_int]),
+    "icamd_bn_train_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "icamd_bn_eval_coeffs": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "icamd_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
+    "icamd_bn_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
+    "icamd_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "icamd_maxpool3x3s2_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "icamd_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "icamd_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "icamd_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "icamd_pack_input": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
+    "icamd_softmax_xent": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
+    "icamd_step_metrics": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "icamd_grad_norm_workspace_bytes": (c_size_t, []),
+    "icamd_grad_norm": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P]),
+    "icamd_adamw_ema": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int,
+                                c_float, c_float, _P, _P, c_int, _P]),
+    "icamd_lerp": (c_int, [_P, _P, c_longlong, c_float, _P, _P]),
+    "icamd_f32_to_bf16": (c_int, [_P, _P, c_longlong, _P]),
+    "icamd_colsum": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libicamd.so and bind every symbol of include/icamd.h; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IcamdError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.icamd_abi_version() != 1:
+        raise IcamdError("libicamd.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise IcamdError(f"{what} failed: {ERRORS.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise IcamdError("the imageclassification_amd compute path needs an AMD GPU (gfx950); none is visible")

@@ -1,0 +1,127 @@
+/* icamd.h -- C ABI of the MI355X (gfx950) training-step kernels.
+ *
+ * Drop-in boundary for ONE hot path of abelxiaoxing/ImageClassification: the per-step compute of
+ * engine.py:train_one_epoch / evaluate (reference: /root/reference/engine.py:10-225).  The reference has no
+ * FFI of its own (it is pure Python on torch); these entry points are what a binding for that path would
+ * bind: every device-side operation the step performs, as plain C functions over raw device pointers.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch data_ptr()), 16-byte aligned;
+ *   - activations are NHWC bf16 (raw 16-bit patterns); parameters, gradients and optimizer state are fp32;
+ *     filters handed to the conv kernels are bf16 [Cout][KH][KW][Cin] ("shadow" copies the optimizer emits);
+ *   - `stream` is a hipStream_t passed as void*; functions only enqueue work: they never allocate,
+ *     never synchronise, never throw.  Return 0 on success, ICAMD_ERR_* otherwise;
+ *   - workspaces are caller-owned; sizes come from the *_workspace_bytes queries;
+ *   - all floating-point reductions are order-fixed (no float atomics): results are bitwise reproducible.
+ */
+#ifndef ICAMD_H
+#define ICAMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICAMD_OK 0
+#define ICAMD_ERR_BAD_ARG 1
+#define ICAMD_ERR_UNSUPPORTED 2
+#define ICAMD_ERR_WORKSPACE 3
+#define ICAMD_ERR_LAUNCH 4
+
+int icamd_abi_version(void);
+
+/* ---- convolution (replaces ATen conv2d fwd / dgrad / wgrad under model(samples), loss.backward():
+ *      /root/reference/engine.py:48,51,64,72; model built at train.py:194) ---------------------------- */
+typedef struct icamd_conv_desc {
+  int N, IH, IW, Cin;   /* input  [N, IH, IW, Cin]  (Cin == 8 for the zero-padded RGB stem, else Cin % 64 == 0) */
+  int OH, OW, Cout;     /* output [N, OH, OW, Cout] (Cout % 8 == 0)                                             */
+  int KH, KW, stride, pad;
+} icamd_conv_desc;
+
+/* number of rows of the per-channel statistics partials a forward call writes: ceil(N*OH*OW / 128) */
+int icamd_conv2d_stats_rows(const icamd_conv_desc* d);
+
+/* y = conv(x, w) (+ bias[co]) (+ addend, same shape as y), rounded once to bf16.
+ * stats (optional): float [stats_rows][2][Cout] <- per-128-pixel-tile sum and sum of squares of the ROUNDED y
+ * (BatchNorm batch statistics, consumed by icamd_bn_train_finalize). */
+int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                     const void* addend, float* stats, void* stream);
+
+/* dx = conv_transpose(dy, w) (+ addend shaped like dx).  w_t is the [Cin][KH][KW][Cout] transposed bf16 filter
+ * (icamd_filter_transpose).  Requires Cout % 64 == 0. */
+int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
+                       void* stream);
+
+size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d);
+/* dw (fp32 [Cout][KH][KW][Cin]) = (accumulate ? dw : 0) + sum over pixels of dy (x) x */
+int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* table-driven batched filter transpose [Cout][T][Cin] -> [Cin][T][Cout] (bf16).
+ * descs: int64[nlayers][8] = {src_off, dst_off, Cout, T, Cin, 0,0,0} (element offsets);
+ * jobs: int32[njobs][2] = {layer, first destination element}, each job covers 4096 destination elements. */
+int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
+                           void* stream);
+
+/* ---- BatchNorm / ReLU / residual (timm BatchNorm2d + ReLU layers under the same reference calls) -------- */
+size_t icamd_bn_workspace_bytes(int C);
+/* training-mode finalize from the conv epilogue partials: batch mean / biased var -> mean, invstd, and the
+ * folded scale = gamma*invstd, shift = beta - mean*scale; running stats updated with `momentum`
+ * (unbiased variance), as torch.nn.functional.batch_norm(training=True). */
+int icamd_bn_train_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                            float* mean, float* invstd, float* scale, float* shift, void* workspace, void* stream);
+int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* out = act(y*scale[c] + shift[c] (+ residual)), act = ReLU if relu else identity */
+int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                   long long numel, int C, int relu, void* stream);
+size_t icamd_bn_bwd_workspace_bytes(long long rows, int C);
+/* g = dout * [act > 0] (act == NULL with relu: mask recomputed from y*scale+shift > 0);
+ * dgamma = sum g*xhat, dbeta = sum g, dy = scale*(g - mean(g) - xhat*mean(g*xhat)); gout (optional) <- g */
+int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
+                 const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
+                 long long rows, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- pooling ---------------------------------------------------------------------------------------- */
+int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
+int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream);
+int icamd_avgpool_fwd(const void* x, void* out, int N, int HW, int C, void* stream);
+int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* stream);
+
+/* ---- input packing + mixup/cutmix (replaces samples.to(device) + timm Mixup.__call__, engine.py:40-44) -- */
+/* x: fp32 NCHW [B,Cin,H,W] (device) -> out: bf16 NHWC [B,H,W,8]; mode 0 none, 1 mixup(lam), 2 cutmix(box) */
+int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                     int xl, int xh, void* stream);
+
+/* ---- loss + metrics (criterion engine.py:49,52,178,181; accuracy / TP-FP-FN engine.py:82-97,184-196) ---- */
+/* logits bf16 [B][ld]; targets int64; target distribution lam*onehot_s(y1) + (1-lam)*onehot_s(y2).
+ * loss_rows float[B]; pred int32[B] (optional argmax); dlogits bf16 [B][ld] (optional) = (softmax - t)*gscale */
+int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* y1, const int64_t* y2, float lam,
+                       float smoothing, float gscale, float* loss_rows, int32_t* pred, void* dlogits, void* stream);
+/* mean loss (fixed order) -> loss_out, finite flag, loss_log[log_slot]; unless skipped for a non-finite loss:
+ * acc_f64[0]+=loss, [1]+=1, [2]+=correct/B, [3]+=correct, [4]+=B ; counts int32[3][C] = TP, FP, FN */
+int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_t* target, int B, int C,
+                       float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
+                       int log_slot, int respect_skip, void* stream);
+
+/* ---- optimizer (optimizer.step / zero_grad / model_ema.update, engine.py:74-77; utils.py:433-468) ------- */
+size_t icamd_grad_norm_workspace_bytes(void);
+/* out[0] = ||g||_2 * inv_scale ; out[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0) */
+int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm, void* workspace, float* out,
+                    void* stream);
+/* torch.optim.AdamW step (decoupled wd, bias correction with `step` >= 1) on flat arenas of n (% 4 == 0)
+ * floats, fused with the ModelEmaV3 lerp (ema may be NULL) and the bf16 shadow write (shadow may be NULL).
+ * Gradient is scaled by gscale * clip[1] (clip may be NULL).  Skipped when *finite_flag == 0. */
+int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
+                    float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
+                    const int32_t* finite_flag, int zero_grad, void* stream);
+int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream);
+int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
+int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICAMD_H */

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (gfx950) GPU; run with -m gpu on the GPU box")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a gpu-marked test on a GPU-less host is a configuration error, not a pass: skip loudly
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible (gpu tests run on the MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
