@@ -31,7 +31,7 @@ int icamd_softmax_xent_launch(const bf16_t* logits, int ld, int B, int C, const 
                               hipStream_t s);
 int icamd_step_metrics_launch(const float* loss_rows, const int* pred, const long long* target, int B, int C,
                               float* loss_out, int* finite_out, double* acc_f64, int* counts, float* loss_log,
-                              int log_slot, int respect_skip, hipStream_t s);
+                              int log_slot, int log_stride, int respect_skip, hipStream_t s);
 int icamd_grad_norm_launch(const float* g, long long n, float inv_scale, float max_norm, double* partial, float* out,
                            hipStream_t s);
 int icamd_adamw_ema_launch(float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n, float lr,
@@ -262,11 +262,12 @@ int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* 
 
 int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_t* target, int B, int C,
                        float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
-                       int log_slot, int respect_skip, void* stream) {
-  if (loss_rows == nullptr || loss_out == nullptr || finite_out == nullptr || acc_f64 == nullptr || B <= 0) return ICAMD_ERR_BAD_ARG;
+                       int log_slot, int log_stride, int respect_skip, void* stream) {
+  if (loss_out == nullptr || finite_out == nullptr || acc_f64 == nullptr || B <= 0) return ICAMD_ERR_BAD_ARG;
   if (pred != nullptr && target == nullptr) return ICAMD_ERR_BAD_ARG;
+  if (loss_rows == nullptr && pred == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_step_metrics_launch(loss_rows, pred, (const long long*)target, B, C, loss_out, finite_out, acc_f64, counts,
-                                   loss_log, log_slot, respect_skip, (hipStream_t)stream);
+                                   loss_log, log_slot, log_stride, respect_skip, (hipStream_t)stream);
 }
 
 size_t icamd_grad_norm_workspace_bytes(void) { return 512 * sizeof(double); }

@@ -86,30 +86,36 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
                                                            const long long* __restrict__ target, int B, int C,
                                                            float* __restrict__ loss_out, int* __restrict__ finite_out,
                                                            double* __restrict__ acc_f64, int* __restrict__ counts,
-                                                           float* __restrict__ loss_log, int log_slot, int respect_skip) {
+                                                           float* __restrict__ loss_log, int log_slot, int log_stride,
+                                                           int respect_skip) {
   __shared__ double red[256];
   __shared__ int cred[256];
   __shared__ int s_finite;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < B; i += 256) s += (double)loss_rows[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+  const bool have_loss = loss_rows != nullptr;
+  if (have_loss) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) s += (double)loss_rows[i];
+    red[threadIdx.x] = s;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const float mean = (float)(red[0] / (double)B);
-    const int fin = isfinite(mean) ? 1 : 0;
-    *loss_out = mean;
-    *finite_out = fin;
-    s_finite = fin;
-    if (loss_log != nullptr) loss_log[log_slot] = mean;
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float mean = (float)(red[0] / (double)B);
+      const int fin = isfinite(mean) ? 1 : 0;
+      *loss_out = mean;
+      *finite_out = fin;
+      s_finite = fin;
+      if (loss_log != nullptr) loss_log[log_slot] = mean;
+    }
+  } else if (threadIdx.x == 0) {
+    s_finite = *finite_out;   // metrics-only call: honour the flag the loss call of this step left behind
   }
   __syncthreads();
   if (respect_skip && !s_finite) return;
   if (pred == nullptr) {
-    if (threadIdx.x == 0) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
+    if (threadIdx.x == 0 && have_loss) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
     return;
   }
   int correct = 0;
@@ -131,9 +137,9 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    acc_f64[0] += (double)*loss_out;
-    acc_f64[1] += 1.0;
+    if (have_loss) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
     acc_f64[2] += (double)((float)cred[0] / (float)B);
+    if (loss_log != nullptr && log_stride > 0) loss_log[log_stride + log_slot] = (float)cred[0] / (float)B;
     acc_f64[3] += (double)cred[0];
     acc_f64[4] += (double)B;
   }
@@ -301,9 +307,9 @@ int icamd_softmax_xent_launch(const bf16_t* logits, int ld, int B, int C, const 
 
 int icamd_step_metrics_launch(const float* loss_rows, const int* pred, const long long* target, int B, int C,
                               float* loss_out, int* finite_out, double* acc_f64, int* counts, float* loss_log,
-                              int log_slot, int respect_skip, hipStream_t s) {
+                              int log_slot, int log_stride, int respect_skip, hipStream_t s) {
   hipLaunchKernelGGL(step_metrics_kernel, dim3(1), dim3(256), 0, s, loss_rows, pred, target, B, C, loss_out, finite_out,
-                     acc_f64, counts, loss_log, log_slot, respect_skip);
+                     acc_f64, counts, loss_log, log_slot, log_stride, respect_skip);
   return icamd_launch_status();
 }
 

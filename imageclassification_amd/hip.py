@@ -54,7 +54,7 @@ _SIGNATURES = {
     "icamd_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "icamd_pack_input": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
     "icamd_softmax_xent": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
-    "icamd_step_metrics": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "icamd_step_metrics": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "icamd_grad_norm_workspace_bytes": (c_size_t, []),
     "icamd_grad_norm": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P]),
     "icamd_adamw_ema": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int,

@@ -1,0 +1,585 @@
+"""ResNet-18/34/50 on the gfx950 kernels: static layer lists with hand-written forward and backward.
+
+The reference builds its network with timm.create_model (/root/reference/train.py:194) and runs it through
+autograd (engine.py:48,51,64,72); there is no model code in the reference tree.  Here a model is a flat list
+of layer records over four flat arenas (fp32 parameters, fp32 gradients, bf16 "shadow" filters the conv
+kernels read, fp32 BatchNorm buffers) and every layer's forward/backward is one or more C-ABI calls
+(include/icamd.h).  No autograd graph, no torch ops on the step path.
+
+Architecture = timm/torchvision ResNet v1.5 (stride on the 3x3 of a bottleneck), BatchNorm eps 1e-5,
+momentum 0.1, parameter names identical to timm's (`conv1.weight`, `layer1.0.bn1.weight`, ..., `fc.bias`) so
+state_dicts interchange with the CPU oracle and with timm checkpoints.
+
+Data layout in HBM: activations NHWC bf16; filters [Cout][KH][KW][Cin] (stem Cin zero-padded 3->8, FC rows
+zero-padded to a multiple of 64); everything 256 B aligned inside the arenas.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+ARCHS = {
+    "resnet18": ("basic", [2, 2, 2, 2]),
+    "resnet34": ("basic", [3, 4, 6, 3]),
+    "resnet50": ("bottleneck", [3, 4, 6, 3]),
+}
+
+
+def _align(n, a):
+    return (n + a - 1) // a * a
+
+
+class _Param:
+    """One logical parameter: a slice of the flat arenas plus its torch-layout shape."""
+    __slots__ = ("name", "offset", "numel", "torch_shape", "kind", "padded_shape")
+
+    def __init__(self, name, offset, numel, torch_shape, kind, padded_shape):
+        self.name, self.offset, self.numel = name, offset, numel
+        self.torch_shape, self.kind, self.padded_shape = torch_shape, kind, padded_shape
+
+
+class _Conv:
+    """Convolution record. weight param in arena layout [Cout_p][KH][KW][Cin_p]."""
+
+    def __init__(self, name, cin, cout, k, stride, pad, cin_p=None, cout_p=None, bias=False):
+        self.name = name
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.cin_p = cin_p or cin
+        self.cout_p = cout_p or cout
+        self.has_bias = bias
+        self.w = None      # _Param
+        self.b = None
+        self.wt_offset = None  # offset into the transposed shadow arena (None: no data gradient needed)
+        self.descs = {}    # (N, IH, IW) -> ConvDesc
+
+    def desc(self, N, IH, IW):
+        key = (N, IH, IW)
+        d = self.descs.get(key)
+        if d is None:
+            d = hip.conv_desc(N, IH, IW, self.cin_p, self.cout_p, self.k, self.k, self.stride, self.pad)
+            self.descs[key] = d
+        return d
+
+
+class _BN:
+    def __init__(self, name, c):
+        self.name, self.c = name, c
+        self.weight = self.bias = None  # _Param
+        self.buf_offset = None          # running_mean at buf_offset, running_var at buf_offset + c
+        self.stat_offset = None         # mean, invstd, scale, shift in the per-model stat arena (4*c floats)
+
+
+class ResNet:
+    """HIP ResNet. `model(x)` runs the forward and returns bf16 logits [B, num_classes] (a view)."""
+
+    def __init__(self, arch="resnet50", num_classes=1000, device="cuda", zero_init_last=True, seed=None):
+        hip.require_gpu()
+        self.lib = hip.load()
+        self.arch = arch
+        self.num_classes = num_classes
+        self.device = torch.device(device)
+        self.training = True
+        block, layers = ARCHS[arch]
+        self.block = block
+        self.expansion = 4 if block == "bottleneck" else 1
+        self.ncls_p = _align(num_classes, 64)
+        self._build_graph(layers)
+        self._allocate()
+        self.num_batches_tracked = 0
+        self._ws = {}
+        self._streams_ready = False
+        self.grad_ready_hook = None   # called with (param_offset_lo, param_offset_hi) as gradients complete
+        self.init_weights(zero_init_last=zero_init_last, seed=seed)
+
+    # ------------------------------------------------------------------ structure
+    def _build_graph(self, layers):
+        self.convs, self.bns = [], []
+        self.stem_conv = self._conv("conv1", 3, 64, 7, 2, 3, cin_p=8)
+        self.stem_bn = self._bn("bn1", 64)
+        self.blocks = []
+        inplanes = 64
+        for li, (planes, nblocks) in enumerate(zip([64, 128, 256, 512], layers)):
+            for bi in range(nblocks):
+                stride = 2 if (bi == 0 and li > 0) else 1
+                name = f"layer{li + 1}.{bi}"
+                outplanes = planes * self.expansion
+                blk = {"name": name, "stride": stride}
+                if self.block == "bottleneck":
+                    blk["convs"] = [self._conv(f"{name}.conv1", inplanes, planes, 1, 1, 0),
+                                    self._conv(f"{name}.conv2", planes, planes, 3, stride, 1),
+                                    self._conv(f"{name}.conv3", planes, outplanes, 1, 1, 0)]
+                    blk["bns"] = [self._bn(f"{name}.bn1", planes), self._bn(f"{name}.bn2", planes),
+                                  self._bn(f"{name}.bn3", outplanes)]
+                else:
+                    blk["convs"] = [self._conv(f"{name}.conv1", inplanes, planes, 3, stride, 1),
+                                    self._conv(f"{name}.conv2", planes, planes, 3, 1, 1)]
+                    blk["bns"] = [self._bn(f"{name}.bn1", planes), self._bn(f"{name}.bn2", planes)]
+                if stride != 1 or inplanes != outplanes:
+                    blk["down_conv"] = self._conv(f"{name}.downsample.0", inplanes, outplanes, 1, stride, 0)
+                    blk["down_bn"] = self._bn(f"{name}.downsample.1", outplanes)
+                self.blocks.append(blk)
+                inplanes = outplanes
+        self.feat_dim = inplanes
+        self.fc = self._conv("fc", inplanes, self.num_classes, 1, 1, 0, cout_p=self.ncls_p, bias=True)
+
+    def _conv(self, name, cin, cout, k, stride, pad, cin_p=None, cout_p=None, bias=False):
+        c = _Conv(name, cin, cout, k, stride, pad, cin_p, cout_p, bias)
+        self.convs.append(c)
+        return c
+
+    def _bn(self, name, c):
+        b = _BN(name, c)
+        self.bns.append(b)
+        return b
+
+    def _allocate(self):
+        dev = self.device
+        # parameter order = timm/torchvision module order (conv, bn, ..., downsample, fc)
+        order = [self.stem_conv, self.stem_bn]
+        for blk in self.blocks:
+            for c, b in zip(blk["convs"], blk["bns"]):
+                order += [c, b]
+            if "down_conv" in blk:
+                order += [blk["down_conv"], blk["down_bn"]]
+        order.append(self.fc)
+        self.params = OrderedDict()
+        off = 0
+
+        def add(name, torch_shape, kind, padded_shape):
+            nonlocal off
+            numel = 1
+            for s in padded_shape:
+                numel *= s
+            p = _Param(name, off, numel, tuple(torch_shape), kind, tuple(padded_shape))
+            self.params[name] = p
+            off = _align(off + numel, 64)  # 256 B alignment of every fp32 slice
+            return p
+
+        boff = 0
+        soff = 0
+        for m in order:
+            if isinstance(m, _Conv):
+                wname = m.name + ".weight"
+                m.w = add(wname, (m.cout, m.cin, m.k, m.k), "conv", (m.cout_p, m.k, m.k, m.cin_p))
+                if m.has_bias:
+                    m.b = add(m.name + ".bias", (m.cout,), "vec", (m.cout_p,))
+            else:
+                m.weight = add(m.name + ".weight", (m.c,), "vec", (m.c,))
+                m.bias = add(m.name + ".bias", (m.c,), "vec", (m.c,))
+                m.buf_offset = boff
+                boff = _align(boff + 2 * m.c, 64)
+                m.stat_offset = soff
+                soff = _align(soff + 4 * m.c, 64)
+        self.n_params = off
+        self.param_arena = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_arena = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        self.buffer_arena = torch.zeros(max(boff, 64), dtype=torch.float32, device=dev)
+        self.stat_arena = torch.zeros(max(soff, 64), dtype=torch.float32, device=dev)
+        # transposed filters for the data-gradient kernels (every conv except the stem)
+        toff = 0
+        descs, jobs = [], []
+        for m in self.convs:
+            if m is self.stem_conv:
+                continue
+            m.wt_offset = toff
+            T = m.k * m.k
+            descs.append([m.w.offset, toff, m.cout_p, T, m.cin_p, 0, 0, 0])
+            for s in range(0, m.w.numel, 4096):
+                jobs.append([len(descs) - 1, s])
+            toff = _align(toff + m.w.numel, 128)
+        self.shadow_t = torch.zeros(toff, dtype=torch.bfloat16, device=dev)
+        self._tr_descs = torch.tensor(descs, dtype=torch.int64, device=dev)
+        self._tr_jobs = torch.tensor(jobs, dtype=torch.int32, device=dev)
+        self._tr_njobs = len(jobs)
+
+    # ------------------------------------------------------------------ parameters / state_dict
+    def init_weights(self, zero_init_last=True, seed=None):
+        """timm ResNet.init_weights: Kaiming-normal (fan_out, relu) convs, BN weight 1 / bias 0, zero-init of the
+        last BN weight of each residual block, nn.Linear default init for the classifier."""
+        g = torch.Generator()
+        if seed is not None:
+            g.manual_seed(seed)
+        else:
+            g.manual_seed(torch.initial_seed() % (2 ** 63))
+        sd = OrderedDict()
+        for name, p in self.params.items():
+            if p.kind == "conv" and not name.startswith("fc."):
+                cout, cin, k, _ = p.torch_shape
+                std = math.sqrt(2.0 / (cout * k * k))
+                sd[name] = torch.randn(p.torch_shape, generator=g) * std
+            elif name == "fc.weight":
+                bound = 1.0 / math.sqrt(p.torch_shape[1])
+                sd[name] = (torch.rand(p.torch_shape[0], p.torch_shape[1], generator=g) * 2 - 1) * bound
+            elif name == "fc.bias":
+                bound = 1.0 / math.sqrt(self.feat_dim)
+                sd[name] = (torch.rand(p.torch_shape, generator=g) * 2 - 1) * bound
+            elif name.endswith(".weight"):
+                sd[name] = torch.ones(p.torch_shape)
+            else:
+                sd[name] = torch.zeros(p.torch_shape)
+        if zero_init_last:
+            for blk in self.blocks:
+                sd[blk["bns"][-1].name + ".weight"].zero_()
+        for b in self.bns:
+            sd[b.name + ".running_mean"] = torch.zeros(b.c)
+            sd[b.name + ".running_var"] = torch.ones(b.c)
+            sd[b.name + ".num_batches_tracked"] = torch.tensor(0)
+        self.load_state_dict(sd)
+
+    def _to_arena_layout(self, p, t):
+        t = t.detach().to(torch.float32).cpu()
+        if p.kind == "conv":
+            if t.dim() == 2:
+                t = t[:, :, None, None]
+            cout, cin, kh, kw = t.shape
+            full = torch.zeros(p.padded_shape)
+            full[:cout, :, :, :cin] = t.permute(0, 2, 3, 1)
+            return full.flatten()
+        full = torch.zeros(p.padded_shape)
+        full[: t.numel()] = t.flatten()
+        return full
+
+    def _from_arena_layout(self, p, flat):
+        t = flat.reshape(p.padded_shape)
+        if p.kind == "conv":
+            cout, cin = p.torch_shape[0], p.torch_shape[1]
+            t = t[:cout, :, :, :cin].permute(0, 3, 1, 2).contiguous()
+            if p.name == "fc.weight":
+                t = t.reshape(cout, cin)
+            return t
+        return t[: p.torch_shape[0]].clone()
+
+    def load_state_dict(self, sd, strict=True):
+        host = self.param_arena.cpu()
+        missing = []
+        for name, p in self.params.items():
+            if name not in sd:
+                missing.append(name)
+                continue
+            host[p.offset:p.offset + p.numel] = self._to_arena_layout(p, sd[name])
+        bufs = self.buffer_arena.cpu()
+        for b in self.bns:
+            for j, key in enumerate(("running_mean", "running_var")):
+                k = f"{b.name}.{key}"
+                if k in sd:
+                    bufs[b.buf_offset + j * b.c: b.buf_offset + (j + 1) * b.c] = sd[k].detach().float().cpu()
+                else:
+                    missing.append(k)
+        k = f"{self.bns[0].name}.num_batches_tracked"
+        if k in sd:
+            self.num_batches_tracked = int(sd[k])
+        if strict and missing:
+            raise KeyError(f"missing keys in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        self.param_arena.copy_(host)
+        self.buffer_arena.copy_(bufs)
+        self.refresh_shadow()
+        return missing
+
+    def state_dict(self):
+        host = self.param_arena.cpu()
+        bufs = self.buffer_arena.cpu()
+        sd = OrderedDict()
+        by_module = OrderedDict()
+        for name, p in self.params.items():
+            by_module.setdefault(name.rsplit(".", 1)[0], []).append(p)
+        bn_by_name = {b.name: b for b in self.bns}
+        for mod, plist in by_module.items():
+            for p in plist:
+                sd[p.name] = self._from_arena_layout(p, host[p.offset:p.offset + p.numel])
+            if mod in bn_by_name:
+                b = bn_by_name[mod]
+                sd[mod + ".running_mean"] = bufs[b.buf_offset:b.buf_offset + b.c].clone()
+                sd[mod + ".running_var"] = bufs[b.buf_offset + b.c:b.buf_offset + 2 * b.c].clone()
+                sd[mod + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked)
+        return sd
+
+    def named_parameters(self):
+        """(name, fp32 arena view) pairs; the views alias the flat parameter arena."""
+        for name, p in self.params.items():
+            yield name, self.param_arena[p.offset:p.offset + p.numel]
+
+    def parameters(self):
+        for _, v in self.named_parameters():
+            yield v
+
+    def grad_of(self, name):
+        """Gradient of a parameter in torch layout (host copy), for tests and checkpoint tools."""
+        p = self.params[name]
+        return self._from_arena_layout(p, self.grad_arena[p.offset:p.offset + p.numel].cpu())
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 filters (and their transposes) from the fp32 master parameters."""
+        s = hip.stream_ptr()
+        hip.check(self.lib.icamd_f32_to_bf16(self.param_arena.data_ptr(), self.shadow.data_ptr(), self.n_params, s),
+                  "f32_to_bf16")
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        hip.check(self.lib.icamd_filter_transpose(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
+                                                  self._tr_descs.data_ptr(), self._tr_jobs.data_ptr(), self._tr_njobs,
+                                                  hip.stream_ptr()), "filter_transpose")
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, N, H, W):
+        key = (N, H, W)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev = self.device
+        lib = self.lib
+        ws = {"N": N, "H": H, "W": W}
+
+        def act(n, h, w, c):
+            return torch.empty(n, h, w, c, dtype=torch.bfloat16, device=dev)
+
+        ws["x8"] = act(N, H, W, 8)
+        d0 = self.stem_conv.desc(N, H, W)
+        ws["y0"] = act(N, d0.OH, d0.OW, 64)
+        ws["a0"] = act(N, d0.OH, d0.OW, 64)
+        PH, PW = (d0.OH - 1) // 2 + 1, (d0.OW - 1) // 2 + 1
+        ws["p0"] = act(N, PH, PW, 64)
+        ws["p0_idx"] = torch.empty(N, PH, PW, 64, dtype=torch.uint8, device=dev)
+        max_act = max(ws["y0"].numel(), ws["x8"].numel())
+        max_stats = lib.icamd_conv2d_stats_rows(ctypes.byref(d0)) * 2 * 64
+        max_wg = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d0))
+        max_bnb = lib.icamd_bn_bwd_workspace_bytes(N * d0.OH * d0.OW, 64)
+        h, w = PH, PW
+        blocks_ws = []
+        for blk in self.blocks:
+            b = {}
+            ih, iw = h, w
+            ys, acts = [], []
+            for ci, conv in enumerate(blk["convs"]):
+                d = conv.desc(N, ih, iw)
+                ys.append(act(N, d.OH, d.OW, conv.cout_p))
+                acts.append(act(N, d.OH, d.OW, conv.cout_p))
+                max_act = max(max_act, ys[-1].numel())
+                max_stats = max(max_stats, lib.icamd_conv2d_stats_rows(ctypes.byref(d)) * 2 * conv.cout_p)
+                max_wg = max(max_wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+                max_bnb = max(max_bnb, lib.icamd_bn_bwd_workspace_bytes(N * d.OH * d.OW, conv.cout_p))
+                ih, iw = d.OH, d.OW
+            b["y"], b["a"] = ys, acts
+            if "down_conv" in blk:
+                dd = blk["down_conv"].desc(N, h, w)
+                b["yd"] = act(N, dd.OH, dd.OW, blk["down_conv"].cout_p)
+                b["ad"] = act(N, dd.OH, dd.OW, blk["down_conv"].cout_p)
+                max_stats = max(max_stats, lib.icamd_conv2d_stats_rows(ctypes.byref(dd)) * 2 * blk["down_conv"].cout_p)
+                max_wg = max(max_wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(dd)))
+                max_bnb = max(max_bnb, lib.icamd_bn_bwd_workspace_bytes(N * dd.OH * dd.OW, blk["down_conv"].cout_p))
+            blocks_ws.append(b)
+            h, w = ih, iw
+        ws["blocks"] = blocks_ws
+        ws["final_hw"] = (h, w)
+        ws["pooled"] = torch.empty(N, self.feat_dim, dtype=torch.bfloat16, device=dev)
+        ws["logits"] = torch.zeros(N, self.ncls_p, dtype=torch.bfloat16, device=dev)
+        dfc = self.fc.desc(N, 1, 1)
+        max_wg = max(max_wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(dfc)))
+        ws["stats"] = torch.empty(max_stats, dtype=torch.float32, device=dev)
+        ws["bn_ws"] = torch.empty(lib.icamd_bn_workspace_bytes(2048), dtype=torch.uint8, device=dev)
+        ws["wgrad_ws"] = torch.empty(max_wg, dtype=torch.uint8, device=dev)
+        ws["wgrad_ws_bytes"] = max_wg
+        ws["bnb_ws"] = torch.empty(max_bnb, dtype=torch.uint8, device=dev)
+        ws["bnb_ws_bytes"] = max_bnb
+        ws["max_act"] = max_act
+        # loss / metric scratch
+        ws["loss_rows"] = torch.empty(N, dtype=torch.float32, device=dev)
+        ws["pred"] = torch.empty(N, dtype=torch.int32, device=dev)
+        ws["dlogits"] = torch.zeros(N, self.ncls_p, dtype=torch.bfloat16, device=dev)
+        ws["dpooled"] = torch.empty(N, self.feat_dim, dtype=torch.bfloat16, device=dev)
+        ws["scale_shift_eval"] = torch.empty(2 * 2048, dtype=torch.float32, device=dev)
+        self._ws[key] = ws
+        return ws
+
+    def _grad_buffers(self, ws):
+        """Seven activation-sized scratch buffers shared by the whole backward pass (allocated on first use)."""
+        if "gbuf" not in ws:
+            n = ws["max_act"]
+            ws["gbuf"] = [torch.empty(n, dtype=torch.bfloat16, device=self.device) for _ in range(7)]
+        return ws["gbuf"]
+
+    # ------------------------------------------------------------------ primitive wrappers
+    def _w(self, conv):
+        return self.shadow.data_ptr() + 2 * conv.w.offset
+
+    def _wt(self, conv):
+        return self.shadow_t.data_ptr() + 2 * conv.wt_offset
+
+    def _pf(self, p):  # fp32 param pointer
+        return self.param_arena.data_ptr() + 4 * p.offset
+
+    def _gf(self, p):  # fp32 grad pointer
+        return self.grad_arena.data_ptr() + 4 * p.offset
+
+    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s):
+        """y = conv(x); out = act(bn(y) (+ residual)). Training: batch statistics from the conv epilogue."""
+        lib = self.lib
+        d = conv.desc(N, IH, IW)
+        st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
+        c = bn.c
+        mean, invstd, scale, shift = st, st + 4 * c, st + 8 * c, st + 12 * c
+        if self.training:
+            stats = ws["stats"].data_ptr()
+            hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x, self._w(conv), y.data_ptr(), None, None, stats, s), conv.name)
+            rows = lib.icamd_conv2d_stats_rows(ctypes.byref(d))
+            rm = self.buffer_arena.data_ptr() + 4 * bn.buf_offset
+            hip.check(lib.icamd_bn_train_finalize(stats, rows, c, float(N * d.OH * d.OW), self._pf(bn.weight),
+                                                  self._pf(bn.bias), rm, rm + 4 * c, BN_MOMENTUM, BN_EPS, mean, invstd,
+                                                  scale, shift, ws["bn_ws"].data_ptr(), s), bn.name)
+        else:
+            hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x, self._w(conv), y.data_ptr(), None, None, None, s), conv.name)
+            rm = self.buffer_arena.data_ptr() + 4 * bn.buf_offset
+            scale = ws["scale_shift_eval"].data_ptr()
+            shift = scale + 4 * 2048
+            hip.check(lib.icamd_bn_eval_coeffs(c, self._pf(bn.weight), self._pf(bn.bias), rm, rm + 4 * c, BN_EPS, scale,
+                                               shift, s), bn.name)
+        hip.check(lib.icamd_bn_apply(y.data_ptr(), scale, shift, residual, out.data_ptr(), y.numel(), c, int(relu), s),
+                  bn.name)
+        return d
+
+    # ------------------------------------------------------------------ forward
+    def pack(self, x_nchw, mix=None):
+        """fp32 NCHW device tensor -> packed NHWC bf16 (channels zero-padded to 8), with optional mixup/cutmix."""
+        N, C, H, W = x_nchw.shape
+        ws = self._workspace(N, H, W)
+        mode, lam, box = (0, 1.0, (0, 0, 0, 0)) if mix is None else mix
+        hip.check(self.lib.icamd_pack_input(x_nchw.data_ptr(), ws["x8"].data_ptr(), N, C, H, W, mode, float(lam),
+                                            int(box[0]), int(box[1]), int(box[2]), int(box[3]), hip.stream_ptr()), "pack")
+        return ws
+
+    def forward_packed(self, ws):
+        lib = self.lib
+        s = hip.stream_ptr()
+        N, H, W = ws["N"], ws["H"], ws["W"]
+        if self.training:
+            self.num_batches_tracked += 1
+        d0 = self._conv_bn_fwd(ws, self.stem_conv, self.stem_bn, ws["x8"].data_ptr(), N, H, W, ws["y0"], ws["a0"], None,
+                               True, s)
+        hip.check(lib.icamd_maxpool3x3s2_fwd(ws["a0"].data_ptr(), ws["p0"].data_ptr(),
+                                             ws["p0_idx"].data_ptr() if self.training else None, N, d0.OH, d0.OW, 64, s),
+                  "maxpool")
+        x = ws["p0"]
+        h, w = x.shape[1], x.shape[2]
+        for blk, b in zip(self.blocks, ws["blocks"]):
+            b["in"] = x
+            b["in_hw"] = (h, w)
+            convs, bns = blk["convs"], blk["bns"]
+            if "down_conv" in blk:
+                self._conv_bn_fwd(ws, blk["down_conv"], blk["down_bn"], x.data_ptr(), N, h, w, b["yd"], b["ad"], None,
+                                  False, s)
+                idn = b["ad"]
+            else:
+                idn = x
+            cur, ch, cw = x, h, w
+            for i, (conv, bn) in enumerate(zip(convs, bns)):
+                last = i == len(convs) - 1
+                d = self._conv_bn_fwd(ws, conv, bn, cur.data_ptr(), N, ch, cw, b["y"][i], b["a"][i],
+                                      idn.data_ptr() if last else None, True, s)
+                cur, ch, cw = b["a"][i], d.OH, d.OW
+            x, h, w = cur, ch, cw
+        hip.check(lib.icamd_avgpool_fwd(x.data_ptr(), ws["pooled"].data_ptr(), N, h * w, self.feat_dim, s), "avgpool")
+        dfc = self.fc.desc(N, 1, 1)
+        hip.check(lib.icamd_conv2d_fwd(ctypes.byref(dfc), ws["pooled"].data_ptr(), self._w(self.fc),
+                                       ws["logits"].data_ptr(), self._pf(self.fc.b), None, None, s), "fc")
+        return ws["logits"]
+
+    def __call__(self, x_nchw):
+        ws = self.pack(x_nchw.to(self.device, dtype=torch.float32).contiguous())
+        logits = self.forward_packed(ws)
+        return logits[:, : self.num_classes]
+
+    # ------------------------------------------------------------------ backward
+    def backward_packed(self, ws, accumulate=False):
+        """Backward from ws['dlogits'] (bf16 [N, ncls_p]); fills the flat fp32 gradient arena.
+        Gradients become final in reverse layer order; `grad_ready_hook(lo, hi)` is called as ranges complete."""
+        lib = self.lib
+        s = hip.stream_ptr()
+        N = ws["N"]
+        acc = int(bool(accumulate))
+        wsp, wsb = ws["wgrad_ws"].data_ptr(), ws["wgrad_ws_bytes"]
+        bws, bwb = ws["bnb_ws"].data_ptr(), ws["bnb_ws_bytes"]
+        D0, D1, G, T, Y, Y2, DA = (b.data_ptr() for b in self._grad_buffers(ws))
+        hook = self.grad_ready_hook
+
+        def wgrad(conv, x_ptr, dy_ptr, n, ih, iw):
+            d = conv.desc(n, ih, iw)
+            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, s),
+                      conv.name + " wgrad")
+
+        def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw):
+            d = conv.desc(n, ih, iw)
+            hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, s),
+                      conv.name + " dgrad")
+
+        def bn_bwd(bn, dout_ptr, act_ptr, y, dy_ptr, gout_ptr, relu):
+            st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
+            c = bn.c
+            rows = y.numel() // c
+            hip.check(lib.icamd_bn_bwd(dout_ptr, act_ptr, y.data_ptr(), st, st + 4 * c, st + 8 * c, st + 12 * c,
+                                       self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, rows, c, int(relu), acc,
+                                       bws, bwb, s), bn.name + " bwd")
+
+        # classifier
+        dl = ws["dlogits"].data_ptr()
+        wgrad(self.fc, ws["pooled"].data_ptr(), dl, N, 1, 1)
+        hip.check(lib.icamd_colsum(dl, N, self.ncls_p, self.ncls_p, self._gf(self.fc.b), acc, s), "fc bias grad")
+        dgrad(self.fc, dl, ws["dpooled"].data_ptr(), None, N, 1, 1)
+        if hook:
+            hook(self.fc.w.offset, self.n_params)
+        fh, fw = ws["final_hw"]
+        dout, other = D0, D1
+        hip.check(lib.icamd_avgpool_bwd(ws["dpooled"].data_ptr(), dout, N, fh * fw, self.feat_dim, s), "avgpool bwd")
+
+        for blk, b in zip(reversed(self.blocks), reversed(ws["blocks"])):
+            convs, bns = blk["convs"], blk["bns"]
+            h, w = b["in_hw"]
+            xin = b["in"]
+            nconv = len(convs)
+            # spatial sizes seen by each conv's input
+            hw_in = [(h, w)]
+            for conv in convs[:-1]:
+                d = conv.desc(N, *hw_in[-1])
+                hw_in.append((d.OH, d.OW))
+            # last BN (+ residual + ReLU): mask from the stored block output
+            bn_bwd(bns[-1], dout, b["a"][-1].data_ptr(), b["y"][-1], Y, G, True)
+            for i in range(nconv - 1, 0, -1):
+                x_i = b["a"][i - 1]
+                wgrad(convs[i], x_i.data_ptr(), Y, N, *hw_in[i])
+                dgrad(convs[i], Y, DA, None, N, *hw_in[i])
+                # BN + ReLU with no residual in front of the ReLU: mask recomputed from y
+                bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], Y, None, True)
+            wgrad(convs[0], xin.data_ptr(), Y, N, h, w)
+            if "down_conv" in blk:
+                bn_bwd(blk["down_bn"], G, None, b["yd"], Y2, None, False)
+                wgrad(blk["down_conv"], xin.data_ptr(), Y2, N, h, w)
+                dgrad(blk["down_conv"], Y2, T, None, N, h, w)
+                dgrad(convs[0], Y, other, T, N, h, w)
+            else:
+                dgrad(convs[0], Y, other, G, N, h, w)
+            if hook:
+                hook(convs[0].w.offset, None)
+            dout, other = other, dout
+
+        # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
+        d0 = self.stem_conv.desc(N, ws["H"], ws["W"])
+        hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
+        bn_bwd(self.stem_bn, DA, None, ws["y0"], Y, None, True)
+        wgrad(self.stem_conv, ws["x8"].data_ptr(), Y, N, ws["H"], ws["W"])
+        if hook:
+            hook(0, None)

@@ -1,0 +1,92 @@
+"""Optimizer construction for the HIP step (reference surface: /root/reference/optim_factory.py:23-122).
+
+The reference puts EVERY trainable parameter (biases and BatchNorm affine terms included) in one "decay"
+group with weight_decay = wd and forces the optimizer-level weight decay to 0 (optim_factory.py:23-55), then
+builds torch.optim.AdamW with default betas/eps (`--opt_eps/--opt_betas` are parsed but never forwarded,
+train.py:224-229).  Here that is one fused kernel over the model's flat fp32 arenas (icamd_adamw_ema), which
+also applies the ModelEmaV3 lerp and writes the bf16 filters the conv kernels read.
+"""
+import torch
+
+from . import hip
+
+
+def get_parameter_groups(model, weight_decay=1e-5):
+    """One group named "decay" holding every parameter (reference optim_factory.py:23-47)."""
+    return [{"weight_decay": weight_decay, "params": list(model.parameters()), "name": "decay"}]
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, amsgrad off) on flat arenas.
+
+    Protocol used by train_one_epoch (reference engine.py:33-38,74-75,101-110): `param_groups[i]["lr"]`,
+    `["weight_decay"]` are rewritten every micro-step from the schedule arrays; `step()`; `zero_grad()`.
+    """
+
+    def __init__(self, model, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.lib = hip.load()
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": betas, "eps": eps, "name": "decay",
+                              "params": [0]}]
+        n = model.n_params
+        dev = model.param_arena.device
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self._gn_ws = torch.empty(self.lib.icamd_grad_norm_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.norm_clip = torch.ones(2, dtype=torch.float32, device=dev)  # [grad norm, clip coefficient]
+
+    # -- the pieces of NativeScaler.__call__ that touch gradients (reference utils.py:438-442,456-468)
+    def measure_grad_norm(self, max_norm=None, grad_scale=1.0):
+        """Global L2 norm of all gradients (x grad_scale) -> norm_clip[0]; norm_clip[1] = clip coefficient
+        min(1, max_norm/(norm+1e-6)) when max_norm is given, else 1."""
+        m = self.model
+        hip.check(self.lib.icamd_grad_norm(m.grad_arena.data_ptr(), m.n_params, float(grad_scale),
+                                           float(max_norm) if max_norm else 0.0, self._gn_ws.data_ptr(),
+                                           self.norm_clip.data_ptr(), hip.stream_ptr()), "grad_norm")
+        return self.norm_clip[0]
+
+    def step(self, model_ema=None, grad_scale=1.0, use_clip=False, finite_flag=None, zero_grad=False):
+        g = self.param_groups[0]
+        m = self.model
+        self.step_count += 1
+        ema_ptr = None
+        decay = 0.0
+        if model_ema is not None:
+            ema_ptr = model_ema.param_arena.data_ptr()
+            decay = model_ema.decay
+        hip.check(self.lib.icamd_adamw_ema(m.param_arena.data_ptr(), m.grad_arena.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), ema_ptr, m.shadow.data_ptr(), m.n_params,
+                                           float(g["lr"]), float(g["weight_decay"]), float(g["betas"][0]),
+                                           float(g["betas"][1]), float(g["eps"]), self.step_count, float(grad_scale),
+                                           float(decay), self.norm_clip.data_ptr() if use_clip else None,
+                                           None if finite_flag is None else finite_flag.data_ptr(), int(zero_grad),
+                                           hip.stream_ptr()), "adamw_ema")
+        m.refresh_transposed()
+        if model_ema is not None:
+            model_ema.after_fused_update(m, finite_flag)
+
+    def zero_grad(self, set_to_none=True):
+        # gradients are overwritten (not accumulated) by the next backward unless update_freq > 1
+        self.model.grad_arena.zero_()
+
+    def state_dict(self):
+        return {"state": {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()},
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        self.step_count = int(st["step"])
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g.update(src)
+
+
+def create_optimizer(opt, lr, weight_decay, model, filter_bias_and_bn=True):
+    """`adamw` (the default recipe, reference train.py:50, optim_factory.py:74-75) is the fused path.
+    The other 19 optimizer names of the reference need timm/apex classes and are outside this hot path."""
+    name = opt.lower().split("_")[-1]
+    if name != "adamw":
+        raise ValueError(f"optimizer '{opt}' is not part of the MI355X hot path (only adamw is fused); see DESIGN.md")
+    return FusedAdamW(model, lr=lr, weight_decay=weight_decay)

@@ -101,10 +101,13 @@ int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, in
 int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* y1, const int64_t* y2, float lam,
                        float smoothing, float gscale, float* loss_rows, int32_t* pred, void* dlogits, void* stream);
 /* mean loss (fixed order) -> loss_out, finite flag, loss_log[log_slot]; unless skipped for a non-finite loss:
- * acc_f64[0]+=loss, [1]+=1, [2]+=correct/B, [3]+=correct, [4]+=B ; counts int32[3][C] = TP, FP, FN */
+ * acc_f64[0]+=loss, [1]+=1, [2]+=correct/B, [3]+=correct, [4]+=B ; counts int32[3][C] = TP, FP, FN.
+ * loss_rows == NULL: metrics-only call (uses the finite flag already in *finite_out; acc[0], acc[1] untouched);
+ * pred == NULL: loss-only call.  loss_log[log_slot] <- loss; loss_log[log_stride + log_slot] <- correct/B
+ * (log_stride > 0). */
 int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_t* target, int B, int C,
                        float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
-                       int log_slot, int respect_skip, void* stream);
+                       int log_slot, int log_stride, int respect_skip, void* stream);
 
 /* ---- optimizer (optimizer.step / zero_grad / model_ema.update, engine.py:74-77; utils.py:433-468) ------- */
 size_t icamd_grad_norm_workspace_bytes(void);
