@@ -1,0 +1,176 @@
+"""Headline benchmark: images/sec (whole node) of ResNet-50 bf16 training at 224x224, batch 256 per GPU
+(BASELINE.json configs[1]; N>1 = configs[2], one process per GPU over RCCL/xGMI, weak scaling).
+
+A "step" is one pass of the hot path (engine.train_one_epoch body: input pack, forward, label-smoothed loss,
+backward, gradient all-reduce, fused AdamW, device-side metrics) over one synthetic batch already resident in
+HBM.  Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel class, timed live with HIP events
+on the launch stream over the timed region; `cpu_baseline` is the CPU oracle of the same step (torch-CPU fp32
+restatement of the reference loop) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_flops_per_image(net, hw):
+    """Algorithmic MACs*2 of every conv/FC forward at true (unpadded) channel counts."""
+    total = 0
+    h = w = hw
+    layers = []
+
+    def add(conv, ih, iw):
+        oh = (ih + 2 * conv.pad - conv.k) // conv.stride + 1
+        ow = (iw + 2 * conv.pad - conv.k) // conv.stride + 1
+        layers.append((conv.name, 2 * oh * ow * conv.cout * conv.cin * conv.k * conv.k))
+        return oh, ow
+
+    h, w = add(net.stem_conv, h, w)
+    h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    for blk in net.blocks:
+        ih, iw = h, w
+        if "down_conv" in blk:
+            add(blk["down_conv"], h, w)
+        for conv in blk["convs"]:
+            ih, iw = add(conv, ih, iw)
+        h, w = ih, iw
+    add(net.fc, 1, 1)
+    return layers
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--hw", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from imageclassification_amd import hip
+    from imageclassification_amd.ddp import DistributedDataParallel
+    from imageclassification_amd.engine import train_one_epoch
+    from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
+    from imageclassification_amd.nets import ResNet
+    from imageclassification_amd.optim_factory import create_optimizer
+    from imageclassification_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
+
+    lib = hip.load()
+    C, B, HW = 1000, args.batch, args.hw
+    net = ResNet(args.arch, C, device=str(device), seed=88)
+    model = DistributedDataParallel(net) if world > 1 else net
+    opt = create_optimizer("adamw", 1e-3, 5e-4, net)
+    crit = LabelSmoothingCrossEntropy(0.1)
+    total_steps = args.warmup + args.steps
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        lr = cosine_scheduler(1e-3, 1e-6, 1, total_steps, warmup_epochs=0)
+        wd = cosine_scheduler(5e-4, 5e-6, 1, total_steps)
+    # synthetic pool, device resident (reference seed convention: 88 + rank, train.py:83,116)
+    g = torch.Generator(device=device).manual_seed(88 + rank)
+    pool = [(torch.randn(B, 3, HW, HW, generator=g, device=device),
+             torch.randint(0, C, (B,), generator=g, device=device)) for _ in range(4)]
+
+    def run(nsteps, start):
+        loader = [pool[i % len(pool)] for i in range(nsteps)]
+        with contextlib.redirect_stdout(sink):
+            return train_one_epoch(model, crit, loader, opt, device, 0, NativeScalerWithGradNormCount(), None, None, None,
+                                   start_steps=start, lr_schedule_values=lr, wd_schedule_values=wd,
+                                   num_training_steps_per_epoch=nsteps, update_freq=1, use_amp=True, num_classes=C)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup:
+        run(args.warmup, 0)
+    hip.prof_collect()
+    lib.icamd_prof_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    stats = run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.icamd_prof_enable(0)
+    prof = hip.prof_collect()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        layers = conv_flops_per_image(net, HW)
+        fwd_flops = sum(f for _, f in layers) * B           # per step, all conv/FC forward launches
+        stem_flops = layers[0][1] * B
+        algo = {"conv_fwd": fwd_flops, "conv_dgrad": fwd_flops - stem_flops, "conv_wgrad": fwd_flops}
+        kern = {}
+        for k, (ms, calls) in prof.items():
+            if calls:
+                kern[k] = {"ms_per_step": ms / args.steps, "calls_per_step": calls / args.steps}
+        mfma_classes = [k for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in kern]
+        dom = max(mfma_classes, key=lambda k: kern[k]["ms_per_step"])
+        ach = algo[dom] / (kern[dom]["ms_per_step"] * 1e-3) / 1e12
+        per_launch_flops = algo[dom] / kern[dom]["calls_per_step"]
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2),
+                    "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
+        for k in mfma_classes:
+            kern[k]["tflops"] = round(algo[k] / (kern[k]["ms_per_step"] * 1e-3) / 1e12, 2)
+        for k in kern:
+            kern[k]["ms_per_step"] = round(kern[k]["ms_per_step"], 3)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle.engine_ref import time_cpu_training
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+            with contextlib.redirect_stdout(sink):
+                ips, threads, sps = time_cpu_training(args.arch, 32, HW, C, warmup=1, steps=args.cpu_steps, threads=ncpu)
+            cpu = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+                   "sample": f"{args.cpu_steps} steps of batch 32 (1 warm-up), torch-CPU fp32 restatement of engine.py "
+                             f"train_one_epoch, {args.arch} {HW}x{HW}, AdamW+label smoothing"}
+        out = {"metric": "images/sec (whole node) ResNet-50 bf16 224^2 training", "value": round(value, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, "
+                                      f"label smoothing 0.1, 1000 classes (BASELINE configs[{1 if world == 1 else 2}])",
+                          "global_batch": B * world, "parallelism": f"dp{world}"},
+               "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+               "train_stats": {k: round(v, 5) for k, v in stats.items()}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,31 @@ int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, cons
                                   int njobs, hipStream_t s);
 int icamd_colsum_launch(const bf16_t* x, int rows, int ld, int cols, float* out, int accumulate, hipStream_t s);
 
+
+// ---- optional in-process kernel timing (HIP events on the launch stream), used by bench.py ------------------
+#include <vector>
+namespace {
+enum ProfClass { PC_IGEMM_FWD = 0, PC_IGEMM_DGRAD, PC_WGRAD, PC_BN_FINALIZE, PC_BN_APPLY, PC_BN_BWD, PC_POOL, PC_PACK,
+                 PC_LOSS, PC_OPTIM, PC_MISC, PC_COUNT };
+struct ProfRec { int cls; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+  int cls; hipStream_t s; hipEvent_t a; bool on;
+  ProfScope(int c, void* stream) : cls(c), s((hipStream_t)stream), on(g_prof_on) {
+    if (on) { a = prof_event(); (void)hipEventRecord(a, s); }
+  }
+  ~ProfScope() {
+    if (on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, s); g_prof_recs.push_back({cls, a, b}); }
+  }
+};
+}  // namespace
+
 namespace {
 
 bool conv_desc_ok(const icamd_conv_desc* d) {
@@ -63,6 +88,24 @@ extern "C" {
 
 int icamd_abi_version(void) { return 1; }
 
+int icamd_prof_enable(int on) { g_prof_on = on != 0; return ICAMD_OK; }
+int icamd_prof_classes(void) { return PC_COUNT; }
+// Synchronises the recorded events, adds per-class elapsed ms / call counts into the arrays, clears the log.
+int icamd_prof_collect(double* ms, long long* calls, int n) {
+  if (ms == nullptr || calls == nullptr || n < PC_COUNT) return ICAMD_ERR_BAD_ARG;
+  for (auto& r : g_prof_recs) {
+    (void)hipEventSynchronize(r.b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    ms[r.cls] += (double)t;
+    calls[r.cls] += 1;
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  return ICAMD_OK;
+}
+
 int icamd_conv2d_stats_rows(const icamd_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
   const long long M = (long long)d->N * d->OH * d->OW;
@@ -71,6 +114,7 @@ int icamd_conv2d_stats_rows(const icamd_conv_desc* d) {
 
 int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                      const void* addend, float* stats, void* stream) {
+  ProfScope _prof(PC_IGEMM_FWD, stream);
   if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
   if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   IgemmParams p;
@@ -93,6 +137,7 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
 
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
                        void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
   if (d->Cout % 64 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
@@ -144,6 +189,7 @@ size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
 
 int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_WGRAD, stream);
   if (!conv_desc_ok(d) || x == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
   const size_t need = icamd_conv2d_wgrad_workspace_bytes(d);
   if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
@@ -161,6 +207,7 @@ int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, 
 
 int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
                            void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
   if (src_base == nullptr || dst_base == nullptr || descs == nullptr || jobs == nullptr || njobs < 0) return ICAMD_ERR_BAD_ARG;
   return icamd_filter_transpose_launch((const bf16_t*)src_base, (bf16_t*)dst_base, (const long long*)descs, jobs, njobs,
                                        (hipStream_t)stream);
@@ -172,6 +219,7 @@ size_t icamd_bn_workspace_bytes(int C) { return C > 0 ? (size_t)64 * 2 * C * siz
 int icamd_bn_train_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                             float* mean, float* invstd, float* scale, float* shift, void* workspace, void* stream) {
+  ProfScope _prof(PC_BN_FINALIZE, stream);
   if (partials == nullptr || nrows <= 0 || C <= 0 || count <= 0 || gamma == nullptr || beta == nullptr ||
       mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr || workspace == nullptr)
     return ICAMD_ERR_BAD_ARG;
@@ -181,6 +229,7 @@ int icamd_bn_train_finalize(const float* partials, int nrows, int C, double coun
 
 int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  ProfScope _prof(PC_BN_FINALIZE, stream);
   if (C <= 0 || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr ||
       scale == nullptr || shift == nullptr)
     return ICAMD_ERR_BAD_ARG;
@@ -189,6 +238,7 @@ int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const flo
 
 int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                    long long numel, int C, int relu, void* stream) {
+  ProfScope _prof(PC_BN_APPLY, stream);
   if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || numel <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)residual, (bf16_t*)out, numel, C, relu,
                                (hipStream_t)stream);
@@ -206,6 +256,7 @@ size_t icamd_bn_bwd_workspace_bytes(long long rows, int C) {
 int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
                  const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
                  long long rows, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
   if (dout == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr ||
       dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 || C <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -225,29 +276,34 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
 }
 
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
   if (x == nullptr || out == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
   return icamd_maxpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, argmax, N, IH, IW, C, OH, OW, (hipStream_t)stream);
 }
 
 int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
   if (dout == nullptr || argmax == nullptr || dx == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
   return icamd_maxpool_bwd_launch((const bf16_t*)dout, argmax, (bf16_t*)dx, N, IH, IW, C, OH, OW, (hipStream_t)stream);
 }
 
 int icamd_avgpool_fwd(const void* x, void* out, int N, int HW, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
   if (x == nullptr || out == nullptr || N <= 0 || HW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_avgpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, N, HW, C, (hipStream_t)stream);
 }
 
 int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
   if (dout == nullptr || dx == nullptr || N <= 0 || HW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_avgpool_bwd_launch((const bf16_t*)dout, (bf16_t*)dx, N, HW, C, (hipStream_t)stream);
 }
 
 int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                      int xl, int xh, void* stream) {
+  ProfScope _prof(PC_PACK, stream);
   if (x == nullptr || out == nullptr || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return ICAMD_ERR_BAD_ARG;
   if (mode != 0 && (B % 2) != 0) return ICAMD_ERR_BAD_ARG;  // timm Mixup asserts an even batch
   return icamd_pack_input_launch(x, (bf16_t*)out, B, Cin, H, W, mode, lam, yl, yh, xl, xh, (hipStream_t)stream);
@@ -255,6 +311,7 @@ int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, in
 
 int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* y1, const int64_t* y2, float lam,
                        float smoothing, float gscale, float* loss_rows, int32_t* pred, void* dlogits, void* stream) {
+  ProfScope _prof(PC_LOSS, stream);
   if (logits == nullptr || y1 == nullptr || loss_rows == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_softmax_xent_launch((const bf16_t*)logits, ld, B, C, (const long long*)y1, (const long long*)y2, lam,
                                    smoothing, gscale, loss_rows, pred, (bf16_t*)dlogits, (hipStream_t)stream);
@@ -263,6 +320,7 @@ int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* 
 int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_t* target, int B, int C,
                        float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
                        int log_slot, int log_stride, int respect_skip, void* stream) {
+  ProfScope _prof(PC_LOSS, stream);
   if (loss_out == nullptr || finite_out == nullptr || acc_f64 == nullptr || B <= 0) return ICAMD_ERR_BAD_ARG;
   if (pred != nullptr && target == nullptr) return ICAMD_ERR_BAD_ARG;
   if (loss_rows == nullptr && pred == nullptr) return ICAMD_ERR_BAD_ARG;
@@ -274,6 +332,7 @@ size_t icamd_grad_norm_workspace_bytes(void) { return 512 * sizeof(double); }
 
 int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm, void* workspace, float* out,
                     void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
   if (g == nullptr || n <= 0 || workspace == nullptr || out == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_grad_norm_launch(g, n, inv_scale, max_norm, (double*)workspace, out, (hipStream_t)stream);
 }
@@ -281,22 +340,26 @@ int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm
 int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
                     float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
                     const int32_t* finite_flag, int zero_grad, void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
   if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_adamw_ema_launch(p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
                                 clip, finite_flag, zero_grad, (hipStream_t)stream);
 }
 
 int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
   if (dst == nullptr || src == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_lerp_launch(dst, src, n, w, finite_flag, (hipStream_t)stream);
 }
 
 int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
   if (src == nullptr || dst == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_f32_to_bf16_launch(src, (bf16_t*)dst, n, (hipStream_t)stream);
 }
 
 int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream) {
+  ProfScope _prof(PC_MISC, stream);
   if (x == nullptr || out == nullptr || rows <= 0 || cols <= 0 || ld < cols) return ICAMD_ERR_BAD_ARG;
   return icamd_colsum_launch((const bf16_t*)x, rows, ld, cols, out, accumulate, (hipStream_t)stream);
 }

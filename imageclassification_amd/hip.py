@@ -62,6 +62,9 @@ _SIGNATURES = {
     "icamd_lerp": (c_int, [_P, _P, c_longlong, c_float, _P, _P]),
     "icamd_f32_to_bf16": (c_int, [_P, _P, c_longlong, _P]),
     "icamd_colsum": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    "icamd_prof_enable": (c_int, [c_int]),
+    "icamd_prof_classes": (c_int, []),
+    "icamd_prof_collect": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -106,3 +109,17 @@ def stream_ptr():
 def require_gpu():
     if not torch.cuda.is_available():
         raise IcamdError("the imageclassification_amd compute path needs an AMD GPU (gfx950); none is visible")
+
+
+PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_finalize", "bn_apply", "bn_bwd", "pool", "pack", "loss",
+                "optimizer", "misc")
+
+
+def prof_collect():
+    """{class: (elapsed_ms, calls)} accumulated since the last call (HIP events on the launch stream)."""
+    lib = load()
+    n = lib.icamd_prof_classes()
+    ms = (c_double * n)()
+    calls = (c_longlong * n)()
+    check(lib.icamd_prof_collect(ms, calls, n), "prof_collect")
+    return {PROF_CLASSES[i]: (ms[i], calls[i]) for i in range(n)}

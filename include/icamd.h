@@ -124,6 +124,13 @@ int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t
 int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream);
 
+/* ---- measurement aid (bench.py): HIP-event timing of every entry point on its launch stream ----------------
+ * classes: 0 conv fwd, 1 conv dgrad, 2 conv wgrad(+slab reduce), 3 bn finalize, 4 bn apply, 5 bn bwd, 6 pooling,
+ * 7 input pack, 8 loss/metrics, 9 optimizer (+filter transpose), 10 misc.  collect() adds elapsed ms / calls. */
+int icamd_prof_enable(int on);
+int icamd_prof_classes(void);
+int icamd_prof_collect(double* ms, long long* calls, int n);
+
 #ifdef __cplusplus
 }
 #endif
