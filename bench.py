@@ -51,6 +51,22 @@ def conv_flops_per_image(net, hw):
     return layers
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,8 +127,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model + {len(pool)} synthetic batches resident; warm-up {args.warmup} steps")
     if args.warmup:
         run(args.warmup, 0)
+    log("warm-up done; timing")
     hip.prof_collect()
     lib.icamd_prof_enable(1)
     barrier()
@@ -127,6 +145,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     value = world * B * args.steps / dt
+    log(f"timed {args.steps} steps: {1e3 * dt / args.steps:.2f} ms/step, {value:.1f} img/s")
 
     if rank == 0:
         layers = conv_flops_per_image(net, HW)
@@ -152,7 +171,8 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             from oracle.engine_ref import time_cpu_training
-            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+            ncpu = host_cores()
+            log(f"cpu baseline on {ncpu} threads ...")
             with contextlib.redirect_stdout(sink):
                 ips, threads, sps = time_cpu_training(args.arch, 32, HW, C, warmup=1, steps=args.cpu_steps, threads=ncpu)
             cpu = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
