@@ -168,13 +168,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i], fixed order, 16 B per lane
+// out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]; 16 B per lane; fixed summation order.
+// A block owns OUTS consecutive float4 outputs and splits the S slabs over 256/OUTS slab lanes (4 loads in
+// flight per thread), then folds the lanes through LDS in lane order.
+template <int OUTS>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long n4, int S, int accumulate) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  constexpr int LANES = 256 / OUTS;
+  __shared__ f32x4 red[256];
+  const int o = threadIdx.x % OUTS, l = threadIdx.x / OUTS;
+  const long long i = (long long)blockIdx.x * OUTS + o;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (i < n4) {
+    const f32x4* p = (const f32x4*)slab + i;
+    int k = l;
+    for (; k + 3 * LANES < S; k += 4 * LANES) {
+      a0 += p[(long long)k * n4];
+      a1 += p[(long long)(k + LANES) * n4];
+      a2 += p[(long long)(k + 2 * LANES) * n4];
+      a3 += p[(long long)(k + 3 * LANES) * n4];
+    }
+    for (; k < S; k += LANES) a0 += p[(long long)k * n4];
+  }
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (l == 0 && i < n4) {
     f32x4 s = accumulate ? ((const f32x4*)out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < S; ++k) s += ((const f32x4*)slab)[(long long)k * n4 + i];
+#pragma unroll
+    for (int j = 0; j < LANES; ++j) s += red[j * OUTS + o];
     ((f32x4*)out)[i] = s;
   }
 }
@@ -221,9 +242,12 @@ int icamd_wgrad_launch(WgradParams& p, hipStream_t stream) {
 int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream) {
   if (n % 4 != 0) return ICAMD_ERR_BAD_ARG;
   const long long n4 = n / 4;
-  long long blocks = (n4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, out, n4, S, accumulate);
+  if (n4 >= 64 * 1024) {   // large filters: 64 outputs x 4 slab lanes per block
+    hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, slab, out, n4, S,
+                       accumulate);
+  } else {                 // small filters, many slabs: 16 outputs x 16 slab lanes per block
+    hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, stream, slab, out, n4, S,
+                       accumulate);
+  }
   return icamd_launch_status();
 }

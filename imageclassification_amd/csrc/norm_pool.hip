@@ -12,30 +12,33 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Two-level per-channel reduction of partial rows:  part[nrows][2][C] (fp32) -> out[nchunks][2][C] (fp64)
-// grid = (ceil(C/64), nchunks); block 256 = 64 channels x 4 row lanes
+// grid = (ceil(C/64), nchunks); block 1024 = 64 channels x 16 row lanes (short dependent chains: the kernel is
+// latency-bound, not bandwidth-bound)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, double* __restrict__ out,
-                                                             int nrows, int C, int rows_per_chunk) {
-  __shared__ double red[4][2][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ part, double* __restrict__ out,
+                                                              int nrows, int C, int rows_per_chunk) {
+  __shared__ double red[16][2][64];
+  const int cc = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cc;
   const int rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_chunk;
   const int r1 = min(nrows, r0 + rows_per_chunk);
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int r = r0 + rl; r < r1; r += 4) {
+    for (int r = r0 + rl; r < r1; r += 16) {
       s1 += (double)part[((long long)r * 2 + 0) * C + c];
       s2 += (double)part[((long long)r * 2 + 1) * C + c];
     }
   }
-  red[rl][0][threadIdx.x & 63] = s1;
-  red[rl][1][threadIdx.x & 63] = s2;
+  red[rl][0][cc] = s1;
+  red[rl][1][cc] = s2;
   __syncthreads();
   if (threadIdx.x < 128) {
-    const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
-    const double s = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
-    const int co = blockIdx.x * 64 + cc;
-    if (co < C) out[((long long)blockIdx.y * 2 + which) * C + co] = s;
+    const int which = threadIdx.x >> 6;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][which][cc];
+    if (c < C) out[((long long)blockIdx.y * 2 + which) * C + c] = s;
   }
 }
 
@@ -453,12 +456,12 @@ inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } retu
 // ---------------- host launchers (called from capi.hip) ----------------
 
 int icamd_partials_to_chunks(const float* part, int nrows, int C, double* chunks, int* nchunks_out, hipStream_t s) {
-  // chunk so that each block walks <= 64*4 rows; at most 64 chunks
-  int rows_per_chunk = 256;
+  // at most 64 chunks (the finalize kernels walk them serially)
+  int rows_per_chunk = 128;
   int nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk;
   if (nchunks > 64) { nchunks = 64; rows_per_chunk = (nrows + 63) / 64; nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk; }
   dim3 grid((unsigned)((C + 63) / 64), (unsigned)nchunks);
-  hipLaunchKernelGGL(partial_reduce_kernel, grid, dim3(256), 0, s, part, chunks, nrows, C, rows_per_chunk);
+  hipLaunchKernelGGL(partial_reduce_kernel, grid, dim3(1024), 0, s, part, chunks, nrows, C, rows_per_chunk);
   *nchunks_out = nchunks;
   return icamd_launch_status();
 }
