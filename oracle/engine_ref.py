@@ -132,9 +132,11 @@ class _Meter:
 
 def train_one_epoch_ref(model, criterion, data_loader, optimizer, epoch=0, max_norm=None, model_ema=None, mixup_fn=None,
                         start_steps=0, lr_schedule_values=None, wd_schedule_values=None,
-                        num_training_steps_per_epoch=None, update_freq=1, num_classes=2, trace=None):
+                        num_training_steps_per_epoch=None, update_freq=1, num_classes=2, trace=None, cpu_alias=False):
     """fp32 branch of the reference (use_amp=False, engine.py:70-77: no clipping). Returns the reference's dict
-    plus, in `trace` (a list), one record per executed step: loss, class_acc, cumulative TP/FP/FN."""
+    plus, in `trace` (a list), one record per executed step: loss, class_acc, cumulative TP/FP/FN.
+    cpu_alias=True reproduces what the reference does when device == cpu: `.to(device)` returns the SAME tensor,
+    so `original_samples` aliases the in-place-mixed batch (SURVEY Appx C.2); on a GPU they are separate copies."""
     model.train(True)
     meters = {}
     optimizer.zero_grad()
@@ -151,8 +153,11 @@ def train_one_epoch_ref(model, criterion, data_loader, optimizer, epoch=0, max_n
                 if wd_schedule_values is not None and group["weight_decay"] > 0:
                     group["weight_decay"] = wd_schedule_values[it]
         # engine.py:40-41: on a GPU these are two separate device copies, so the "original" stays un-mixed
-        original_samples, original_targets = samples.clone(), targets.clone()
-        samples = samples.clone()
+        if cpu_alias:
+            original_samples, original_targets = samples, targets
+        else:
+            original_samples, original_targets = samples.clone(), targets.clone()
+            samples = samples.clone()
         if mixup_fn is not None:
             samples, targets = mixup_fn(samples, targets)
         output = model(samples)
