@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     }
     if (relu) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+      for (int e = 0; e < 8; ++e) f[e] = (f[e] < 0.f) ? 0.f : f[e];   // NaN stays NaN, as torch.relu
     }
     u32x4 o;
 #pragma unroll
