@@ -177,3 +177,32 @@ def test_optimizer_factory_surface():
     from imageclassification_amd.optim_factory import create_optimizer
     with pytest.raises(ValueError):
         create_optimizer("lamb", 1e-3, 0.05, None)
+
+
+def test_imagefolder_split_and_eval_transform(tmp_path):
+    """Generated 2-class ImageFolder (the reference's cat/dog set is an external download): class order, per-class
+    equal validation counts (reference datasets.py:12-53) and the eval transform's arithmetic (:139-144)."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from imageclassification_amd import datasets as D
+    rng = np.random.RandomState(0)
+    for cls, n in (("cat", 11), ("dog", 17)):
+        os.makedirs(tmp_path / cls)
+        for i in range(n):
+            Image.fromarray(rng.randint(0, 255, (20, 24, 3), dtype=np.uint8)).save(tmp_path / cls / f"{i:03d}.png")
+    args = SimpleNamespace(data_path=str(tmp_path), train_split_rato=0.8, input_size=16, color_jitter=0.3, reprob=0.25, aa="")
+    train, val, C = D.build_dataset(args)
+    assert C == 2 and len(train) + len(val) == 28
+    vt = [val[i][1] for i in range(len(val))]
+    assert vt.count(0) == vt.count(1) == 2          # round(11 * 0.2) = 2 of EACH class
+    x, y = val[0]
+    assert x.shape == (3, 16, 16) and x.dtype == torch.float32
+    path, _ = val.base.samples[val.indices[0]]
+    img = Image.open(path).convert("RGB").resize((16, 16), Image.BILINEAR)
+    ref = (np.asarray(img, dtype=np.float32) / 255.0 - np.array(D.IMAGENET_DEFAULT_MEAN, dtype=np.float32)) / \
+        np.array(D.IMAGENET_DEFAULT_STD, dtype=np.float32)
+    assert np.allclose(x.numpy(), ref.transpose(2, 0, 1), atol=1e-6)
+    xt, _ = train[0]
+    assert xt.shape == (3, 16, 16) and torch.isfinite(xt).all()
+    with pytest.raises(NotImplementedError):
+        D.TrainTransform(16, auto_augment="rand-m9-mstd0.5-inc1")
