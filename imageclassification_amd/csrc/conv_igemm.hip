@@ -24,13 +24,18 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK = 64;
 
+#ifndef ICAMD_IGEMM_STAGES
+#define ICAMD_IGEMM_STAGES 1   // 1: single LDS stage, overlap comes from 4 workgroups per CU; 2: double buffer, 2 per CU
+#endif
+
 template <int BN, bool CIN8>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? 4 : 2)) void conv_igemm_kernel(const IgemmParams p) {
+  constexpr int NSTAGE = ICAMD_IGEMM_STAGES;
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int EPI_BYTES = BM * BN * 4;
-  constexpr int SMEM_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+  constexpr int EPI_BYTES = (BM / 2) * BN * 4;   // the fp32 output tile goes through LDS in two 64-row halves
+  constexpr int SMEM_BYTES = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
   constexpr int NJ = BN / 32;   // filter-row fragments per wave (wave covers BN/2 channels)
   constexpr int BROWS = BN / 32;  // B staging instructions per wave
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -144,11 +149,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
   const int sw = fr >> 1;  // (row>>1)&7 for every fragment row this lane reads (rows are 16-aligned + fr)
 
   const int nks = p.ksteps;
-  if (nks > 0) stage(0, 0);
-  __syncthreads();  // emits vmcnt(0): stage 0 has landed
-  for (int ks = 0; ks < nks; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+  auto compute = [&](int buf) {
     const unsigned char* sA = smem + buf * STAGE_BYTES;
     const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
@@ -167,24 +168,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
         for (int i = 0; i < 4; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
     }
-    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading this buffer
+  };
+  if constexpr (NSTAGE == 2) {
+    if (nks > 0) stage(0, 0);
+    __syncthreads();  // emits vmcnt(0): stage 0 has landed
+    for (int ks = 0; ks < nks; ++ks) {
+      const int buf = ks & 1;
+      if (ks + 1 < nks) stage(ks + 1, buf ^ 1);
+      compute(buf);
+      __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading this buffer
+    }
+  } else {
+    for (int ks = 0; ks < nks; ++ks) {
+      stage(ks, 0);
+      __syncthreads();  // vmcnt(0) + barrier: the stage has landed for every wave
+      compute(0);
+      __syncthreads();  // all fragment reads done before the buffer is refilled / reused by the epilogue
+    }
   }
 
-  // ---- epilogue: accumulators -> fp32 LDS tile [m][co] (16 B chunks XOR-swizzled by m&7) ----
+  // ---- epilogue: accumulators -> fp32 LDS half-tile [64 m][co] (16 B chunks XOR-swizzled by m&7), twice ----
   constexpr int ROWB = BN * 4;  // bytes per fp32 tile row
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ml = wm * 64 + i * 16 + fr;
-      const int c16 = (wn * (BN / 2) + j * 16 + 4 * fq) >> 2;
-      *(f32x4*)(smem + ml * ROWB + ((c16 ^ (ml & 7)) << 4)) = acc[j][i];
-    }
-  __syncthreads();
-
   constexpr int CPR = BN / 8;          // 8-channel groups per row
   constexpr int RPP = 256 / CPR;       // rows per pass
-  constexpr int NPASS = BM / RPP;
+  constexpr int NPASS = (BM / 2) / RPP;
   const int cp = tid % CPR, rg = tid / CPR;
   const int co = n0 + cp * 8;
   const bool co_ok = co < p.Cout;  // Cout % 8 == 0 (host-checked)
@@ -196,39 +203,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmParams p) {
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int ml = ps * RPP + rg;
-    const int m = m0 + ml;
-    const f32x4 v0 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp) ^ (ml & 7)) << 4));
-    const f32x4 v1 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp + 1) ^ (ml & 7)) << 4));
-    if (m < p.M && co_ok) {
-      const unsigned int n = fdiv((unsigned)m, p.divPQ);
-      const unsigned int rem = m - n * (p.P * p.Q);
-      const unsigned int pp = fdiv(rem, p.divQ);
-      const unsigned int qq = rem - pp * p.Q;
-      const long long pix = ((long long)n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w;
-      const long long off = pix * p.Cout + co;
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-      if (p.addend != nullptr) {
-        const u32x4 a = *(const u32x4*)(p.addend + off);
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(a[e]); v[2 * e + 1] += bf16_hi(a[e]); }
-      }
-      u32x4 o;
+        for (int i = 0; i < 4; ++i) {
+          const int ml = i * 16 + fr;
+          const int c16 = (wn * (BN / 2) + j * 16 + 4 * fq) >> 2;
+          *(f32x4*)(smem + ml * ROWB + ((c16 ^ (ml & 7)) << 4)) = acc[j][i];
+        }
+    }
+    __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-      *(u32x4*)(p.out + off) = o;
-      if (p.stats != nullptr) {
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int ml = ps * RPP + rg;
+      const int m = m0 + half * 64 + ml;
+      const f32x4 v0 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp) ^ (ml & 7)) << 4));
+      const f32x4 v1 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp + 1) ^ (ml & 7)) << 4));
+      if (m < p.M && co_ok) {
+        const unsigned int n = fdiv((unsigned)m, p.divPQ);
+        const unsigned int rem = m - n * (p.P * p.Q);
+        const unsigned int pp = fdiv(rem, p.divQ);
+        const unsigned int qq = rem - pp * p.Q;
+        const long long pix = ((long long)n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w;
+        const long long off = pix * p.Cout + co;
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = bf16_lo(o[e]), hi = bf16_hi(o[e]);
-          s1[2 * e] += lo; s2[2 * e] += lo * lo;
-          s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        if (p.addend != nullptr) {
+          const u32x4 a = *(const u32x4*)(p.addend + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(a[e]); v[2 * e + 1] += bf16_hi(a[e]); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        *(u32x4*)(p.out + off) = o;
+        if (p.stats != nullptr) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = bf16_lo(o[e]), hi = bf16_hi(o[e]);
+            s1[2 * e] += lo; s2[2 * e] += lo * lo;
+            s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+          }
         }
       }
     }
+    if (half == 0) __syncthreads();  // half-tile consumed before the second half overwrites it
   }
 
   if (p.stats != nullptr) {

@@ -30,8 +30,16 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* p0, const un
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+#ifndef ICAMD_WGRAD_STAGES
+#define ICAMD_WGRAD_STAGES 1   // 1: single LDS stage + 3-4 workgroups per CU; 2: double buffer
+#endif
+#ifndef ICAMD_WGRAD_WAVES_PER_SIMD
+#define ICAMD_WGRAD_WAVES_PER_SIMD 3
+#endif
+
 template <int BMK, int BNC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_PER_SIMD : 2)) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int NSTAGE = ICAMD_WGRAD_STAGES;
   constexpr int X_BYTES = BKR * BMK * 2;
   constexpr int Y_BYTES = BKR * BNC * 2;
   constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
@@ -40,7 +48,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int XRPI = 64 / XCPR, YRPI = 64 / YCPR;    // rows per wave-instruction
   constexpr int XJ = BMK / 32, YJ = BNC / 32;          // staging instructions per wave
   constexpr int KR = BMK / 32, CR = BNC / 32;          // 16-wide fragments per wave (kk, co)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wc = wave >> 1;
@@ -124,11 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
 
   const int nsteps = (m_end - m_begin + BKR - 1) / BKR;
-  if (nsteps > 0) stage(m_begin, 0);
-  __syncthreads();
-  for (int st = 0; st < nsteps; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nsteps) stage(m_begin + (st + 1) * BKR, buf ^ 1);
+  auto compute = [&](int buf) {
     const unsigned char* sX = smem + buf * STAGE_BYTES;
     const unsigned char* sY = sX + X_BYTES;
 #pragma unroll
@@ -153,7 +157,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < CR; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
     }
+  };
+  if constexpr (NSTAGE == 2) {
+    if (nsteps > 0) stage(m_begin, 0);
     __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < nsteps) stage(m_begin + (st + 1) * BKR, buf ^ 1);
+      compute(buf);
+      __syncthreads();
+    }
+  } else {
+    for (int st = 0; st < nsteps; ++st) {
+      stage(m_begin + st * BKR, 0);
+      __syncthreads();   // vmcnt(0) + barrier: stage landed
+      compute(0);
+      __syncthreads();   // reads done before the refill
+    }
   }
 
   // D[kk][co]: lane holds co = lane&15, kk = 4*(lane>>4) + reg  -> one 16 B fp32 store per fragment
