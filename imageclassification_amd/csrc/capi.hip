@@ -18,6 +18,9 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
                         long long rows, int C, int relu, int accumulate, float* part, double* chunks, float* c1c2,
                         hipStream_t s);
+int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
+                              const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
+                              long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s);
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s);
 int icamd_maxpool_bwd_launch(const bf16_t* dout, const unsigned char* idx, bf16_t* dx, int N, int IH, int IW, int C, int OH,
@@ -135,13 +138,13 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
   return icamd_igemm_launch(p, (hipStream_t)stream);
 }
 
-int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
-                       void* stream) {
-  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
+                      const icamd_bn_bwd_fuse* f, void* stream) {
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
   if (d->Cout % 64 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
+  float* partials = f ? f->partials : nullptr;
   // one launch per output parity class (ph, pw): pixels h = st*p + ph, w = st*q + pw receive only the taps
   // r with (ph + pad - r) % st == 0, read at dy row p + (ph + pad - r)/st
   for (int ph = 0; ph < st; ++ph)
@@ -158,6 +161,12 @@ int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t
       p.ostr = st; p.ooff_h = ph; p.ooff_w = pw; p.istr = 1;
       p.Ktot = d->KH * d->KW * d->Cout;
       p.KW = d->KW; p.pad = d->pad;
+      if (f != nullptr) {
+        p.bnb_y = (const bf16_t*)f->y; p.bnb_mask = (const bf16_t*)f->mask_src;
+        p.bnb_mean = f->mean; p.bnb_invstd = f->invstd; p.bnb_scale = f->scale; p.bnb_shift = f->shift;
+        p.bnb_relu = f->relu; p.stats = partials;
+        partials += (size_t)((p.M + 127) / 128) * 2 * d->Cin;   // each parity class writes its own partial rows
+      }
       int nt = 0;
       for (int r = 0; r < d->KH; ++r) {
         const int eh = ph + d->pad - r;
@@ -175,6 +184,31 @@ int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t
       if (rc) return rc;
     }
   return ICAMD_OK;
+}
+
+int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
+                       void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  return dgrad_impl(d, dy, w_t, dx, addend, nullptr, stream);
+}
+
+int icamd_conv2d_dgrad_stats_rows(const icamd_conv_desc* d) {
+  if (!conv_desc_ok(d)) return 0;
+  int rows = 0;
+  for (int ph = 0; ph < d->stride; ++ph)
+    for (int pw = 0; pw < d->stride; ++pw) {
+      const long long P = (d->IH - ph + d->stride - 1) / d->stride, Q = (d->IW - pw + d->stride - 1) / d->stride;
+      if (P > 0 && Q > 0) rows += (int)((d->N * P * Q + 127) / 128);
+    }
+  return rows;
+}
+
+int icamd_conv2d_dgrad_bnbwd(const icamd_conv_desc* d, const void* dy, const void* w_t, void* g, const void* addend,
+                             const icamd_bn_bwd_fuse* f, void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  if (f == nullptr || f->y == nullptr || f->mean == nullptr || f->invstd == nullptr || f->partials == nullptr)
+    return ICAMD_ERR_BAD_ARG;
+  return dgrad_impl(d, dy, w_t, g, addend, f, stream);
 }
 
 size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
@@ -273,6 +307,28 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
   return icamd_bn_bwd_launch((const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, mean, invstd, scale, shift, dgamma,
                              dbeta, (bf16_t*)dy, (bf16_t*)gout, rows, C, relu, accumulate, part, chunks, c1c2,
                              (hipStream_t)stream);
+}
+
+// workspace: chunks [64][2][C] doubles | c1,c2 [2][C] floats
+size_t icamd_bn_bwd_apply_workspace_bytes(int C) {
+  return C > 0 ? align_up((size_t)64 * 2 * C * sizeof(double), 256) + align_up((size_t)2 * C * sizeof(float), 256) : 0;
+}
+
+int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, const void* y, const float* mean,
+                               const float* invstd, const float* scale, float* dgamma, float* dbeta, void* dy,
+                               long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (partials == nullptr || nrows <= 0 || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr ||
+      scale == nullptr || dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 ||
+      C <= 0 || C % 8 != 0)
+    return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < icamd_bn_bwd_apply_workspace_bytes(C)) return ICAMD_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  double* chunks = (double*)ws;
+  ws += align_up((size_t)64 * 2 * C * sizeof(double), 256);
+  return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
+                                   (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream);
 }
 
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {

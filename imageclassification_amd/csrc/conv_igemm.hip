@@ -28,13 +28,16 @@ constexpr int BK = 64;
 #define ICAMD_IGEMM_STAGES 1   // 1: single LDS stage, overlap comes from 4 workgroups per CU; 2: double buffer, 2 per CU
 #endif
 
-template <int BN, bool CIN8>
-__global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? 4 : 2)) void conv_igemm_kernel(const IgemmParams p) {
+// EPI 0: out = acc (+bias)(+addend); optional statistics of the rounded outputs (BatchNorm forward).
+// EPI 1: data-gradient with the next BatchNorm-backward fused in: g = (acc + addend) * [ReLU mask], out = g, and the
+//        partial rows hold sum(g) and sum(g * xhat), xhat from the BN input `bnb_y` (BatchNorm backward, pass 1).
+template <int BN, bool CIN8, int EPI>
+__global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) : 2)) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int NSTAGE = ICAMD_IGEMM_STAGES;
   constexpr int A_BYTES = BM * BK * 2;
   constexpr int B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int EPI_BYTES = (BM / 2) * BN * 4;   // the fp32 output tile goes through LDS in two 64-row halves
+  constexpr int EPI_BYTES = BM * BN * 2;   // the rounded bf16 output tile goes through LDS once
   constexpr int SMEM_BYTES = (NSTAGE * STAGE_BYTES > EPI_BYTES) ? NSTAGE * STAGE_BYTES : EPI_BYTES;
   constexpr int NJ = BN / 32;   // filter-row fragments per wave (wave covers BN/2 channels)
   constexpr int BROWS = BN / 32;  // B staging instructions per wave
@@ -187,59 +190,144 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? 4 : 2)) void conv_i
     }
   }
 
-  // ---- epilogue: accumulators -> fp32 LDS half-tile [64 m][co] (16 B chunks XOR-swizzled by m&7), twice ----
-  constexpr int ROWB = BN * 4;  // bytes per fp32 tile row
+  // ---- epilogue ----------------------------------------------------------------------------------------
+  // (1) in the MFMA layout (a lane owns 4 consecutive channels of one pixel): add bias / addend in fp32, round
+  //     ONCE to bf16, and drop the tile into LDS as [128 m][BN] bf16 (16 B chunks XOR-swizzled by m&15);
+  // (2) coalesced pass: each thread takes 8 channels (16 B) of a row from LDS, applies the fused BatchNorm-
+  //     backward mask / accumulates the per-channel statistics, and stores 16 B rows (256 B per 16 lanes).
+  //     Everything pass (2) reads from global memory (BN input, mask) is prefetched before the barrier.
+  // Loads are never placed under a per-lane condition (hipcc would branch around each and wait vmcnt(0) per
+  // load): invalid lanes read a clamped, in-bounds address and discard the value.
+  constexpr int ROWB = BN * 2;         // bytes per bf16 tile row
   constexpr int CPR = BN / 8;          // 8-channel groups per row
   constexpr int RPP = 256 / CPR;       // rows per pass
-  constexpr int NPASS = (BM / 2) / RPP;
+  constexpr int NPASS = BM / RPP;
   const int cp = tid % CPR, rg = tid / CPR;
   const int co = n0 + cp * 8;
   const bool co_ok = co < p.Cout;  // Cout % 8 == 0 (host-checked)
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = (p.bias != nullptr && co_ok) ? p.bias[co + e] : 0.f;
-  float s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
+  // pass-(2) row offsets (elements; the host checks the output tensor has < 2^31 elements) and prefetches
+  int roff[NPASS];
+  u32x4 yv[EPI == 1 ? NPASS : 1], mv[EPI == 1 ? NPASS : 1];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ml = i * 16 + fr;
-          const int c16 = (wn * (BN / 2) + j * 16 + 4 * fq) >> 2;
-          *(f32x4*)(smem + ml * ROWB + ((c16 ^ (ml & 7)) << 4)) = acc[j][i];
-        }
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int m = m0 + ps * RPP + rg;
+    roff[ps] = -1;
+    if (m < p.M && co_ok) {
+      const unsigned int n = fdiv((unsigned)m, p.divPQ);
+      const unsigned int rem = m - n * (p.P * p.Q);
+      const unsigned int pp = fdiv(rem, p.divQ);
+      const unsigned int qq = rem - pp * p.Q;
+      const int pix = (n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w;
+      roff[ps] = pix * p.Cout + co;
     }
-    __syncthreads();
+    if constexpr (EPI == 1) {
+      const int ro = roff[ps] >= 0 ? roff[ps] : 0;
+      yv[ps] = *(const u32x4*)(p.bnb_y + ro);
+      mv[ps] = *(const u32x4*)((p.bnb_mask != nullptr ? p.bnb_mask : p.bnb_y) + ro);
+    }
+  }
+
+  // (1) MFMA-layout adds + rounding + LDS write
+  {
+    const bool has_addend = p.addend != nullptr;   // wave-uniform
+    int moff[4];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int ml = ps * RPP + rg;
-      const int m = m0 + half * 64 + ml;
-      const f32x4 v0 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp) ^ (ml & 7)) << 4));
-      const f32x4 v1 = *(const f32x4*)(smem + ml * ROWB + (((2 * cp + 1) ^ (ml & 7)) << 4));
-      if (m < p.M && co_ok) {
+    for (int i = 0; i < 4; ++i) {
+      moff[i] = 0;   // rows past M read pixel 0 (valid memory); their results are never stored
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      if (has_addend && m < p.M) {
         const unsigned int n = fdiv((unsigned)m, p.divPQ);
         const unsigned int rem = m - n * (p.P * p.Q);
         const unsigned int pp = fdiv(rem, p.divQ);
         const unsigned int qq = rem - pp * p.Q;
-        const long long pix = ((long long)n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w;
-        const long long off = pix * p.Cout + co;
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        moff[i] = ((n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w) * p.Cout;
+      }
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-        if (p.addend != nullptr) {
-          const u32x4 a = *(const u32x4*)(p.addend + off);
+    for (int j = 0; j < NJ; ++j) {
+      const int cl = wn * (BN / 2) + j * 16 + 4 * fq;      // tile-local channel of this lane's 4 values
+      const int cg = n0 + cl;
+      const int cgc = cg < p.Cout ? cg : 0;                 // clamped: loads stay in bounds, values unused
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
+      u32x2 av[4];
+      if (has_addend) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[2 * e] += bf16_lo(a[e]); v[2 * e + 1] += bf16_hi(a[e]); }
+        for (int i = 0; i < 4; ++i) av[i] = *(const u32x2*)(p.addend + moff[i] + cgc);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = acc[j][i] + b4;
+        if (has_addend) {
+          const u32x2 a = av[i];
+          v[0] += bf16_lo(a[0]); v[1] += bf16_hi(a[0]); v[2] += bf16_lo(a[1]); v[3] += bf16_hi(a[1]);
         }
-        u32x4 o;
+        const int ml = wm * 64 + i * 16 + fr;
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        const int slot = cl >> 2;                           // 8 B slot in the row; 16 B chunk = slot >> 1
+        *(u32x2*)(smem + ml * ROWB + ((((slot >> 1) ^ (ml & 15)) & (CPR - 1)) << 4) + ((slot & 1) << 3)) = pk;
+      }
+    }
+  }
+  __syncthreads();
+
+  float s1[8], s2[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
-        *(u32x4*)(p.out + off) = o;
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  float bmu[8], bis[8], bsc[8], bsh[8];
+  if constexpr (EPI == 1) {
+    const int cc = co_ok ? co : 0;
+    const bool from_y = p.bnb_mask == nullptr && p.bnb_relu;   // uniform
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bmu[e] = p.bnb_mean[cc + e];
+      bis[e] = p.bnb_invstd[cc + e];
+      bsc[e] = from_y ? p.bnb_scale[cc + e] : 0.f;
+      bsh[e] = from_y ? p.bnb_shift[cc + e] : 0.f;
+    }
+  }
+
+  // (2) coalesced pass
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int ml = ps * RPP + rg;
+    u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ (ml & 15)) & (CPR - 1)) << 4));
+    if (roff[ps] >= 0) {
+      if constexpr (EPI == 1) {
+        float yy[8], gg[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          yy[2 * e] = bf16_lo(yv[ps][e]); yy[2 * e + 1] = bf16_hi(yv[ps][e]);
+          gg[2 * e] = bf16_lo(o[e]); gg[2 * e + 1] = bf16_hi(o[e]);
+        }
+        if (p.bnb_relu) {
+          if (p.bnb_mask != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (!(bf16_lo(mv[ps][e]) > 0.f)) { gg[2 * e] = 0.f; o[e] &= 0xffff0000u; }
+              if (!(bf16_hi(mv[ps][e]) > 0.f)) { gg[2 * e + 1] = 0.f; o[e] &= 0x0000ffffu; }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              if (!(fmaf(yy[e], bsc[e], bsh[e]) > 0.f)) {
+                gg[e] = 0.f;
+                o[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+              }
+            }
+          }
+        }
+        *(u32x4*)(p.out + roff[ps]) = o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += gg[e];
+          s2[e] += gg[e] * ((yy[e] - bmu[e]) * bis[e]);
+        }
+      } else {
+        *(u32x4*)(p.out + roff[ps]) = o;
         if (p.stats != nullptr) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -250,7 +338,6 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? 4 : 2)) void conv_i
         }
       }
     }
-    if (half == 0) __syncthreads();  // half-tile consumed before the second half overwrites it
   }
 
   if (p.stats != nullptr) {
@@ -272,11 +359,11 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? 4 : 2)) void conv_i
   }
 }
 
-template <int BN, bool CIN8>
+template <int BN, bool CIN8, int EPI>
 int launch(const IgemmParams& p, hipStream_t stream) {
   const int ntm = (p.M + BM - 1) / BM;
   dim3 grid((unsigned)(ntm * p.ntiles_n));
-  hipLaunchKernelGGL((conv_igemm_kernel<BN, CIN8>), grid, dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BN, CIN8, EPI>), grid, dim3(256), 0, stream, p);
   return icamd_launch_status();
 }
 
@@ -290,12 +377,18 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   if (!cin8 && (p.Cin % 64 != 0)) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.N * p.IH * p.IW * p.Cin >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.Cout * p.Ktot >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  if ((long long)p.N * p.OH * p.OW * p.Cout >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if (p.M <= 0 || p.ntaps < 0 || p.ntaps > ICAMD_MAX_TAPS) return ICAMD_ERR_BAD_ARG;
   const int bn = icamd_igemm_pick_bn(p.Cout);
   p.ntiles_n = (p.Cout + bn - 1) / bn;
   p.ksteps = (p.ntaps * p.Cin + BK - 1) / BK;
   p.divPQ = make_fastdiv((unsigned)(p.P * p.Q));
   p.divQ = make_fastdiv((unsigned)p.Q);
-  if (bn == 64) return cin8 ? launch<64, true>(p, stream) : launch<64, false>(p, stream);
-  return cin8 ? launch<128, true>(p, stream) : launch<128, false>(p, stream);
+  if (p.bnb_y != nullptr) {
+    if (cin8 || p.stats == nullptr || p.bnb_mean == nullptr || p.bnb_invstd == nullptr) return ICAMD_ERR_BAD_ARG;
+    if (p.bnb_relu && p.bnb_mask == nullptr && (p.bnb_scale == nullptr || p.bnb_shift == nullptr)) return ICAMD_ERR_BAD_ARG;
+    return bn == 64 ? launch<64, false, 1>(p, stream) : launch<128, false, 1>(p, stream);
+  }
+  if (bn == 64) return cin8 ? launch<64, true, 0>(p, stream) : launch<64, false, 0>(p, stream);
+  return cin8 ? launch<128, true, 0>(p, stream) : launch<128, false, 0>(p, stream);
 }

@@ -13,6 +13,11 @@ struct IgemmParams {
   const bf16_t* addend;  // optional, laid out like out
   const float* bias;     // optional [Cout]
   float* stats;          // optional [ceil(M/128)][2][Cout] partial sum / sum-of-squares of rounded outputs
+  // fused BatchNorm-backward pass 1 (data-gradient launches only; enabled by bnb_y != nullptr)
+  const bf16_t* bnb_y;     // BN input (conv output) of the layer whose output gradient this launch produces
+  const bf16_t* bnb_mask;  // post-activation tensor for the ReLU mask, or nullptr: mask = bnb_y*scale+shift > 0
+  const float *bnb_mean, *bnb_invstd, *bnb_scale, *bnb_shift;
+  int bnb_relu;
   int N, IH, IW, Cin;
   int OH, OW, Cout;
   int P, Q, M;           // output sub-grid and row count N*P*Q

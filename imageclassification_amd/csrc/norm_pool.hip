@@ -534,6 +534,26 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
   return icamd_launch_status();
 }
 
+// BN backward from pass-1 partials produced elsewhere (the fused data-gradient epilogue): finalize + apply pass.
+// g is already masked, so the apply kernel runs without a ReLU mask; shift is unused in that mode.
+int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
+                              const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
+                              long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s) {
+  int nchunks = 0;
+  int rc = icamd_partials_to_chunks(part, nrows, C, chunks, &nchunks, s);
+  if (rc) return rc;
+  float* c1 = c1c2;
+  float* c2 = c1c2 + C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, chunks, nchunks, C,
+                     (double)rows, dgamma, dbeta, c1, c2, accumulate);
+  rc = icamd_launch_status();
+  if (rc) return rc;
+  const long long nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, g, (const bf16_t*)nullptr, y,
+                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, nvec, C / 8, 0);
+  return icamd_launch_status();
+}
+
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s) {
   if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;

@@ -19,6 +19,11 @@ class IcamdError(RuntimeError):
     pass
 
 
+class BnBwdFuse(Structure):
+    _fields_ = [("y", c_void_p), ("mask_src", c_void_p), ("mean", c_void_p), ("invstd", c_void_p), ("scale", c_void_p),
+                ("shift", c_void_p), ("partials", c_void_p), ("relu", c_int)]
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("N", "IH", "IW", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad")]
 
@@ -39,6 +44,8 @@ _SIGNATURES = {
     "icamd_conv2d_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "icamd_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "icamd_conv2d_dgrad_stats_rows": (c_int, [POINTER(ConvDesc)]),
+    "icamd_conv2d_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, POINTER(BnBwdFuse), _P]),
     "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "icamd_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_size_t, _P]),
     "icamd_filter_transpose": (c_int, [_P, _P, _P, _P, c_int, _P]),
@@ -48,6 +55,8 @@ _SIGNATURES = {
     "icamd_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "icamd_bn_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "icamd_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "icamd_bn_bwd_apply_workspace_bytes": (c_size_t, [c_int]),
+    "icamd_bn_bwd_from_partials": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
     "icamd_maxpool3x3s2_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "icamd_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "icamd_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

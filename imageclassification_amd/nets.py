@@ -395,6 +395,9 @@ class ResNet:
         ws["bn_ws"] = torch.empty(lib.icamd_bn_workspace_bytes(2048), dtype=torch.uint8, device=dev)
         ws["wgrad_ws"] = torch.empty(max_wg, dtype=torch.uint8, device=dev)
         ws["wgrad_ws_bytes"] = max_wg
+        ws["bnb_part"] = torch.empty(max_stats + 4 * 2 * 2048, dtype=torch.float32, device=dev)
+        ws["bna_ws_bytes"] = lib.icamd_bn_bwd_apply_workspace_bytes(2048)
+        ws["bna_ws"] = torch.empty(ws["bna_ws_bytes"], dtype=torch.uint8, device=dev)
         ws["bnb_ws"] = torch.empty(max_bnb, dtype=torch.uint8, device=dev)
         ws["bnb_ws_bytes"] = max_bnb
         ws["max_act"] = max_act
@@ -535,6 +538,26 @@ class ResNet:
                                        self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, rows, c, int(relu), acc,
                                        bws, bwb, s), bn.name + " bwd")
 
+        P, pw_bytes = ws["bnb_part"].data_ptr(), ws["bna_ws_bytes"]
+        aws = ws["bna_ws"].data_ptr()
+
+        def dgrad_bnbwd(conv, dy_ptr, g_ptr, addend, n, ih, iw, bn, y, mask_src, relu):
+            """data gradient whose output is the output-gradient of `bn`(+ReLU): fused mask + pass-1 reductions."""
+            d = conv.desc(n, ih, iw)
+            st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
+            c = bn.c
+            f = hip.BnBwdFuse(y.data_ptr(), mask_src, st, st + 4 * c, st + 8 * c, st + 12 * c, P, int(relu))
+            hip.check(lib.icamd_conv2d_dgrad_bnbwd(ctypes.byref(d), dy_ptr, self._wt(conv), g_ptr, addend, ctypes.byref(f), s),
+                      conv.name + " dgrad+bnbwd")
+            return lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d))
+
+        def bn_bwd_from_partials(bn, nrows, g_ptr, y, dy_ptr):
+            st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
+            c = bn.c
+            hip.check(lib.icamd_bn_bwd_from_partials(P, nrows, g_ptr, y.data_ptr(), st, st + 4 * c, st + 8 * c,
+                                                     self._gf(bn.weight), self._gf(bn.bias), dy_ptr, y.numel() // c, c, acc,
+                                                     aws, pw_bytes, s), bn.name + " bwd(apply)")
+
         # classifier
         dl = ws["dlogits"].data_ptr()
         wgrad(self.fc, ws["pooled"].data_ptr(), dl, N, 1, 1)
@@ -546,32 +569,45 @@ class ResNet:
         dout, other = D0, D1
         hip.check(lib.icamd_avgpool_bwd(ws["dpooled"].data_ptr(), dout, N, fh * fw, self.feat_dim, s), "avgpool bwd")
 
-        for blk, b in zip(reversed(self.blocks), reversed(ws["blocks"])):
+        nblk = len(self.blocks)
+        pending_rows = 0   # partial rows left in P by the previous block's fused data gradient (for this block's last BN)
+        for bi in range(nblk - 1, -1, -1):
+            blk, b = self.blocks[bi], ws["blocks"][bi]
             convs, bns = blk["convs"], blk["bns"]
             h, w = b["in_hw"]
             xin = b["in"]
             nconv = len(convs)
-            # spatial sizes seen by each conv's input
             hw_in = [(h, w)]
             for conv in convs[:-1]:
                 d = conv.desc(N, *hw_in[-1])
                 hw_in.append((d.OH, d.OW))
-            # last BN (+ residual + ReLU): mask from the stored block output
-            bn_bwd(bns[-1], dout, b["a"][-1].data_ptr(), b["y"][-1], Y, G, True)
+            if bi == nblk - 1:
+                # last block: its output gradient comes from the average pool: two-pass BN backward with the mask
+                bn_bwd(bns[-1], dout, b["a"][-1].data_ptr(), b["y"][-1], Y, G, True)
+                g_ptr = G
+            else:
+                # `dout` already holds g = masked output gradient and P its pass-1 sums (fused in the producer)
+                bn_bwd_from_partials(bns[-1], pending_rows, dout, b["y"][-1], Y)
+                g_ptr = dout
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
                 wgrad(convs[i], x_i.data_ptr(), Y, N, *hw_in[i])
-                dgrad(convs[i], Y, DA, None, N, *hw_in[i])
-                # BN + ReLU with no residual in front of the ReLU: mask recomputed from y
-                bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], Y, None, True)
+                nrows = dgrad_bnbwd(convs[i], Y, DA, None, N, *hw_in[i], bns[i - 1], b["y"][i - 1], None, True)
+                bn_bwd_from_partials(bns[i - 1], nrows, DA, b["y"][i - 1], Y)
             wgrad(convs[0], xin.data_ptr(), Y, N, h, w)
             if "down_conv" in blk:
-                bn_bwd(blk["down_bn"], G, None, b["yd"], Y2, None, False)
+                bn_bwd(blk["down_bn"], g_ptr, None, b["yd"], Y2, None, False)
                 wgrad(blk["down_conv"], xin.data_ptr(), Y2, N, h, w)
                 dgrad(blk["down_conv"], Y2, T, None, N, h, w)
-                dgrad(convs[0], Y, other, T, N, h, w)
+                addend = T
             else:
-                dgrad(convs[0], Y, other, G, N, h, w)
+                addend = g_ptr
+            if bi > 0:
+                pb, pblk = ws["blocks"][bi - 1], self.blocks[bi - 1]
+                pending_rows = dgrad_bnbwd(convs[0], Y, other, addend, N, h, w, pblk["bns"][-1], pb["y"][-1],
+                                           xin.data_ptr(), True)
+            else:
+                dgrad(convs[0], Y, other, addend, N, h, w)
             if hook:
                 hook(convs[0].w.offset, None)
             dout, other = other, dout

@@ -53,6 +53,22 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
                        void* stream);
 
+/* Data gradient with the NEXT BatchNorm backward's first pass fused into the epilogue: the tensor this call produces
+ * is the output-gradient of a BatchNorm(+residual)+ReLU layer, so the kernel applies that layer's ReLU mask
+ * (mask_src > 0, or y*scale+shift > 0 when mask_src is NULL), stores g = masked gradient, and writes per-tile partial
+ * sums of g and g*xhat (xhat = (y-mean)*invstd) -- consumed by icamd_bn_bwd_from_partials.
+ * partials: float [icamd_conv2d_dgrad_stats_rows(d)][2][Cin]. */
+typedef struct icamd_bn_bwd_fuse {
+  const void* y;         /* that BatchNorm's input (a conv output), shaped like dx                                 */
+  const void* mask_src;  /* post-activation tensor shaped like dx, or NULL                                         */
+  const float *mean, *invstd, *scale, *shift;
+  float* partials;
+  int relu;
+} icamd_bn_bwd_fuse;
+int icamd_conv2d_dgrad_stats_rows(const icamd_conv_desc* d);
+int icamd_conv2d_dgrad_bnbwd(const icamd_conv_desc* d, const void* dy, const void* w_t, void* g, const void* addend,
+                             const icamd_bn_bwd_fuse* f, void* stream);
+
 size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d);
 /* dw (fp32 [Cout][KH][KW][Cin]) = (accumulate ? dw : 0) + sum over pixels of dy (x) x */
 int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
@@ -83,6 +99,13 @@ size_t icamd_bn_bwd_workspace_bytes(long long rows, int C);
 int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
                  const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
                  long long rows, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* second half of the fused form: finalize (dgamma, dbeta, means) + dy = scale*(g - mean(g) - xhat*mean(g*xhat)) */
+size_t icamd_bn_bwd_apply_workspace_bytes(int C);
+int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, const void* y, const float* mean,
+                               const float* invstd, const float* scale, float* dgamma, float* dbeta, void* dy,
+                               long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---- pooling ---------------------------------------------------------------------------------------- */
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);

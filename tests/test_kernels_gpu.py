@@ -445,3 +445,56 @@ def test_colsum_lerp_cast(lib):
     assert lib.icamd_f32_to_bf16(hip.ptr(adev), hip.ptr(o), 1000, hip.stream_ptr()) == 0
     sync()
     assert torch.equal(o.cpu(), a.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 1, 1, 0), (3, 9, 7, 64, 128, 3, 1, 1), (2, 13, 11, 64, 128, 3, 2, 1),
+                                  (2, 14, 14, 256, 512, 1, 2, 0), (2, 12, 12, 256, 64, 1, 1, 0)])
+@pytest.mark.parametrize("mask_mode", ["from_y", "from_act", "none"])
+def test_conv_dgrad_with_fused_bn_backward(lib, case, mask_mode):
+    """icamd_conv2d_dgrad_bnbwd + icamd_bn_bwd_from_partials == data gradient followed by the BatchNorm backward."""
+    hip = _hip()
+    N, H, W, Cin, Cout, k, st, pad = case
+    d = hip.conv_desc(N, H, W, Cin, Cout, k, k, st, pad)
+    g = torch.Generator().manual_seed(80)
+    dy = rnd_bf16(N, d.OH, d.OW, Cout, seed=81)
+    w = rnd_bf16(Cout, k, k, Cin, scale=(1.0 / (k * k * Cout)) ** 0.5, seed=82)
+    w_t = w.permute(3, 1, 2, 0).contiguous()
+    addend = rnd_bf16(N, H, W, Cin, seed=83)
+    ybn = rnd_bf16(N, H, W, Cin, seed=84)                      # the BN input of the layer whose output-grad we produce
+    gamma = torch.rand(Cin, generator=g) + 0.5
+    beta = torch.randn(Cin, generator=g) * 0.3
+    mean, invstd, scale, shift, _, _ = R.bn_train_coeffs(ybn, gamma, beta, torch.zeros(Cin), torch.ones(Cin), 0.1, 1e-5)
+    res = rnd_bf16(N, H, W, Cin, seed=85)
+    relu = mask_mode != "none"
+    act = R.bn_apply(ybn, scale, shift, res if mask_mode == "from_act" else None, relu)
+    # oracle: plain data gradient (+addend), then BN backward with that activation's mask
+    dout = R.conv2d_dgrad(dy, w, (H, W), st, pad, addend)
+    rdy, rdg, rdb, rg = R.bn_bwd(dout, act, ybn, mean, invstd, scale, relu)
+
+    dev = lambda t: t.to(DEV).contiguous()
+    dyd, wtd, addd, ybnd, actd = to_dev_bf16(dy), to_dev_bf16(w_t), to_dev_bf16(addend), to_dev_bf16(ybn), to_dev_bf16(act)
+    md, isd, scd, shd = dev(mean), dev(invstd), dev(scale), dev(shift)
+    rows = lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d))
+    part = torch.full((rows, 2, Cin), float("nan"), device=DEV)
+    gout = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+    f = hip.BnBwdFuse(hip.ptr(ybnd), hip.ptr(actd) if mask_mode == "from_act" else None, hip.ptr(md), hip.ptr(isd),
+                      hip.ptr(scd), hip.ptr(shd), hip.ptr(part), int(relu))
+    assert lib.icamd_conv2d_dgrad_bnbwd(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(gout), hip.ptr(addd),
+                                        ctypes.byref(f), hip.stream_ptr()) == 0
+    wsb = lib.icamd_bn_bwd_apply_workspace_bytes(Cin)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dgam, dbet = torch.zeros(Cin, device=DEV), torch.zeros(Cin, device=DEV)
+    dyo = torch.empty_like(gout)
+    assert lib.icamd_bn_bwd_from_partials(hip.ptr(part), rows, hip.ptr(gout), hip.ptr(ybnd), hip.ptr(md), hip.ptr(isd),
+                                          hip.ptr(scd), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(dyo), N * H * W, Cin, 0,
+                                          hip.ptr(ws), wsb, hip.stream_ptr()) == 0
+    sync()
+    gg = gout.float().cpu()
+    assert torch.isfinite(gg).all() and torch.isfinite(part).all()
+    assert R.rel_l2(gg, rg) <= 1e-3 and R.bf16_close(gg, rg)
+    # reductions are those of the g the kernel itself stored
+    _, dg2, db2, _ = R.bn_bwd(gg, None, ybn, mean, invstd, scale, relu=False)
+    assert R.rel_l2(dgam.cpu(), dg2) <= 1e-4 and R.rel_l2(dbet.cpu(), db2) <= 1e-4
+    assert R.rel_l2(dgam.cpu(), rdg) <= 5e-3 and R.rel_l2(dbet.cpu(), rdb) <= 5e-3
+    got = dyo.float().cpu()
+    assert R.rel_l2(got, rdy) <= 2e-3 and R.bf16_close(got, rdy, ulps=2.0, atol_rms=4e-3)

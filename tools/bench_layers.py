@@ -53,15 +53,25 @@ def main():
         t_d = float("nan")
         if cin != 8:
             t_d = timeit(lambda: hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, s)))
+        t_df = float("nan")
+        if cin != 8:
+            ybn = torch.randn(N, h, h, cin, device="cuda").to(torch.bfloat16)
+            coef = torch.rand(4, cin, device="cuda") + 0.5
+            rows = lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d))
+            part = torch.empty(rows * 2 * cin, device="cuda")
+            use_mask = os.environ.get("FUSE_MASK", "0") == "1"
+            f = hip.BnBwdFuse(ybn.data_ptr(), x.data_ptr() if use_mask else None, coef[0].data_ptr(), coef[1].data_ptr(),
+                              coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), 1)
+            t_df = timeit(lambda: hip.check(lib.icamd_conv2d_dgrad_bnbwd(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, ctypes.byref(f), s)))
         t_w = timeit(lambda: hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 0, ws.data_ptr(), wsb, s)))
         io_gb = (x.numel() + y.numel()) * 2 / 1e9
         name = f"{cin}->{cout} k{k} s{st} {h}x{h} x{cnt}"
-        print(f"{name:34s} {M:8d} {gf:7.1f} | {t_f:8.1f} {gf/t_f*1e-3:6.0f} {io_gb/t_f*1e6:6.0f} | {t_d:8.1f} {gf/t_d*1e-3:6.0f} | {t_w:8.1f} {gf/t_w*1e-3:6.0f}")
+        print(f"{name:34s} {M:8d} {gf:7.1f} | {t_f:8.1f} {gf/t_f*1e3:6.0f} {io_gb/t_f*1e6:6.0f} | {t_d:8.1f} {gf/t_d*1e3:6.0f} fused {t_df:8.1f} | {t_w:8.1f} {gf/t_w*1e3:6.0f}")
         tot["fwd"] += t_f * cnt; totf["fwd"] += gf * cnt
         if cin != 8:
             tot["dgrad"] += t_d * cnt; totf["dgrad"] += gf * cnt
         tot["wgrad"] += t_w * cnt; totf["wgrad"] += gf * cnt
     for k in tot:
-        print(f"total {k}: {tot[k]/1e3:.2f} ms, {totf[k]/tot[k]*1e-3:.0f} TFLOP/s")
+        print(f"total {k}: {tot[k]/1e3:.2f} ms, {totf[k]/tot[k]*1e3:.0f} TFLOP/s")
 
 main()
