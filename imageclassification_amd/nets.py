@@ -21,7 +21,10 @@ import torch
 
 from . import hip
 
+import os
+
 BN_EPS = 1e-5
+_FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
 BN_MOMENTUM = 0.1
 
 ARCHS = {
@@ -511,6 +514,89 @@ class ResNet:
     def backward_packed(self, ws, accumulate=False):
         """Backward from ws['dlogits'] (bf16 [N, ncls_p]); fills the flat fp32 gradient arena.
         Gradients become final in reverse layer order; `grad_ready_hook(lo, hi)` is called as ranges complete."""
+        if _FUSED_BNBWD:
+            return self._backward_packed_fused(ws, accumulate)
+        lib = self.lib
+        s = hip.stream_ptr()
+        N = ws["N"]
+        acc = int(bool(accumulate))
+        wsp, wsb = ws["wgrad_ws"].data_ptr(), ws["wgrad_ws_bytes"]
+        bws, bwb = ws["bnb_ws"].data_ptr(), ws["bnb_ws_bytes"]
+        D0, D1, G, T, Y, Y2, DA = (b.data_ptr() for b in self._grad_buffers(ws))
+        hook = self.grad_ready_hook
+
+        def wgrad(conv, x_ptr, dy_ptr, n, ih, iw):
+            d = conv.desc(n, ih, iw)
+            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, s),
+                      conv.name + " wgrad")
+
+        def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw):
+            d = conv.desc(n, ih, iw)
+            hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, s),
+                      conv.name + " dgrad")
+
+        def bn_bwd(bn, dout_ptr, act_ptr, y, dy_ptr, gout_ptr, relu):
+            st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
+            c = bn.c
+            rows = y.numel() // c
+            hip.check(lib.icamd_bn_bwd(dout_ptr, act_ptr, y.data_ptr(), st, st + 4 * c, st + 8 * c, st + 12 * c,
+                                       self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, rows, c, int(relu), acc,
+                                       bws, bwb, s), bn.name + " bwd")
+
+        # classifier
+        dl = ws["dlogits"].data_ptr()
+        wgrad(self.fc, ws["pooled"].data_ptr(), dl, N, 1, 1)
+        hip.check(lib.icamd_colsum(dl, N, self.ncls_p, self.ncls_p, self._gf(self.fc.b), acc, s), "fc bias grad")
+        dgrad(self.fc, dl, ws["dpooled"].data_ptr(), None, N, 1, 1)
+        if hook:
+            hook(self.fc.w.offset, self.n_params)
+        fh, fw = ws["final_hw"]
+        dout, other = D0, D1
+        hip.check(lib.icamd_avgpool_bwd(ws["dpooled"].data_ptr(), dout, N, fh * fw, self.feat_dim, s), "avgpool bwd")
+
+        for blk, b in zip(reversed(self.blocks), reversed(ws["blocks"])):
+            convs, bns = blk["convs"], blk["bns"]
+            h, w = b["in_hw"]
+            xin = b["in"]
+            nconv = len(convs)
+            # spatial sizes seen by each conv's input
+            hw_in = [(h, w)]
+            for conv in convs[:-1]:
+                d = conv.desc(N, *hw_in[-1])
+                hw_in.append((d.OH, d.OW))
+            # last BN (+ residual + ReLU): mask from the stored block output
+            bn_bwd(bns[-1], dout, b["a"][-1].data_ptr(), b["y"][-1], Y, G, True)
+            for i in range(nconv - 1, 0, -1):
+                x_i = b["a"][i - 1]
+                wgrad(convs[i], x_i.data_ptr(), Y, N, *hw_in[i])
+                dgrad(convs[i], Y, DA, None, N, *hw_in[i])
+                # BN + ReLU with no residual in front of the ReLU: mask recomputed from y
+                bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], Y, None, True)
+            wgrad(convs[0], xin.data_ptr(), Y, N, h, w)
+            if "down_conv" in blk:
+                bn_bwd(blk["down_bn"], G, None, b["yd"], Y2, None, False)
+                wgrad(blk["down_conv"], xin.data_ptr(), Y2, N, h, w)
+                dgrad(blk["down_conv"], Y2, T, None, N, h, w)
+                dgrad(convs[0], Y, other, T, N, h, w)
+            else:
+                dgrad(convs[0], Y, other, G, N, h, w)
+            if hook:
+                hook(convs[0].w.offset, None)
+            dout, other = other, dout
+
+        # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
+        d0 = self.stem_conv.desc(N, ws["H"], ws["W"])
+        hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
+        bn_bwd(self.stem_bn, DA, None, ws["y0"], Y, None, True)
+        wgrad(self.stem_conv, ws["x8"].data_ptr(), Y, N, ws["H"], ws["W"])
+        if hook:
+            hook(0, None)
+
+    def _backward_packed_fused(self, ws, accumulate=False):
+        """Variant that fuses each BatchNorm backward's mask + reduction pass into the epilogue of the data-gradient
+        kernel that produces its output gradient (icamd_conv2d_dgrad_bnbwd + icamd_bn_bwd_from_partials).  Fewer HBM
+        bytes, but the un-pipelined epilogue makes it latency-bound on MI355X today (profiles/ r01 notes): opt-in with
+        ICAMD_FUSED_BNBWD=1."""
         lib = self.lib
         s = hip.stream_ptr()
         N = ws["N"]
