@@ -248,17 +248,19 @@ int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* 
 }
 
 // BN workspace: [64 chunks][2][C] doubles
-size_t icamd_bn_workspace_bytes(int C) { return C > 0 ? (size_t)64 * 2 * C * sizeof(double) : 0; }
+// [64 chunks][2][C] doubles + ceil(C/64) arrival counters (uint32, must be zero before first use; self-resetting)
+static size_t bn_chunk_bytes(int C) { return 256 + align_up((size_t)64 * 2 * C * sizeof(double), 256); }
+size_t icamd_bn_workspace_bytes(int C) { return C > 0 ? bn_chunk_bytes(C) : 0; }
 
 int icamd_bn_train_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                             float* mean, float* invstd, float* scale, float* shift, void* workspace, void* stream) {
   ProfScope _prof(PC_BN_FINALIZE, stream);
   if (partials == nullptr || nrows <= 0 || C <= 0 || count <= 0 || gamma == nullptr || beta == nullptr ||
-      mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr || workspace == nullptr)
+      mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr || workspace == nullptr || C > 4096)
     return ICAMD_ERR_BAD_ARG;
   return icamd_bn_finalize_launch(partials, nrows, C, count, gamma, beta, running_mean, running_var, momentum, eps, mean,
-                                  invstd, scale, shift, (double*)workspace, (hipStream_t)stream);
+                                  invstd, scale, shift, (double*)((char*)workspace + 256), (hipStream_t)stream);
 }
 
 int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
@@ -283,8 +285,7 @@ size_t icamd_bn_bwd_workspace_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
   const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
   const long long nblk = (rows + rpb - 1) / rpb;
-  return align_up((size_t)nblk * 2 * C * sizeof(float), 256) + align_up((size_t)64 * 2 * C * sizeof(double), 256) +
-         align_up((size_t)2 * C * sizeof(float), 256);
+  return align_up((size_t)nblk * 2 * C * sizeof(float), 256) + bn_chunk_bytes(C) + align_up((size_t)2 * C * sizeof(float), 256);
 }
 
 int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
@@ -298,11 +299,12 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
   if (workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
   const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
   const long long nblk = (rows + rpb - 1) / rpb;
+  if (C > 4096) return ICAMD_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
+  double* chunks = (double*)(ws + 256);     // arrival counters live in the first 256 B
+  ws += bn_chunk_bytes(C);
   float* part = (float*)ws;
   ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
-  double* chunks = (double*)ws;
-  ws += align_up((size_t)64 * 2 * C * sizeof(double), 256);
   float* c1c2 = (float*)ws;
   return icamd_bn_bwd_launch((const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, mean, invstd, scale, shift, dgamma,
                              dbeta, (bf16_t*)dy, (bf16_t*)gout, rows, C, relu, accumulate, part, chunks, c1c2,
@@ -311,7 +313,7 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
 
 // workspace: chunks [64][2][C] doubles | c1,c2 [2][C] floats
 size_t icamd_bn_bwd_apply_workspace_bytes(int C) {
-  return C > 0 ? align_up((size_t)64 * 2 * C * sizeof(double), 256) + align_up((size_t)2 * C * sizeof(float), 256) : 0;
+  return C > 0 ? bn_chunk_bytes(C) + align_up((size_t)2 * C * sizeof(float), 256) : 0;
 }
 
 int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, const void* y, const float* mean,
@@ -324,9 +326,10 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
       C <= 0 || C % 8 != 0)
     return ICAMD_ERR_BAD_ARG;
   if (workspace_bytes < icamd_bn_bwd_apply_workspace_bytes(C)) return ICAMD_ERR_WORKSPACE;
+  if (C > 4096) return ICAMD_ERR_UNSUPPORTED;
   char* ws = (char*)workspace;
-  double* chunks = (double*)ws;
-  ws += align_up((size_t)64 * 2 * C * sizeof(double), 256);
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(C);
   return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
                                    (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream);
 }

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
     for (int j = 0; j < XJ; ++j) {
       const int m = mbase + x_row[j];
       const bf16_t* src = zero;
-      if (m < m_end && x_ci[j] >= 0) {
+      if (p.pointwise) {
+        // 1x1 / stride 1 / no padding: output pixel m IS input pixel m -- no index arithmetic at all
+        if (m < m_end && x_ci[j] >= 0) src = x + ((long long)m * p.Cin + x_ci[j]);
+      } else if (m < m_end && x_ci[j] >= 0) {
         const unsigned int n = fdiv((unsigned)m, p.divHW);
         const unsigned int rem = m - n * (p.OH * p.OW);
         const unsigned int oh = fdiv(rem, p.divW);
@@ -255,6 +258,7 @@ int icamd_wgrad_launch(WgradParams& p, hipStream_t stream) {
   p.divW = make_fastdiv((unsigned)p.OW);
   p.divCin = make_fastdiv((unsigned)p.Cin);
   p.divKW = make_fastdiv((unsigned)p.KW);
+  p.pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0) ? 1 : 0;
   if (bmk == 64) return bnc == 64 ? launch<64, 64>(p, stream) : launch<64, 128>(p, stream);
   return bnc == 64 ? launch<128, 64>(p, stream) : launch<128, 128>(p, stream);
 }

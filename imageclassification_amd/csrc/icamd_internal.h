@@ -41,6 +41,7 @@ struct WgradParams {
   int M, Ktot;        // N*OH*OW ; KH*KW*Cin
   int S, rows_per_split;  // split of the m reduction
   int ntiles_k, ntiles_c;
+  int pointwise;      // 1x1, stride 1, pad 0: the gather is the identity
   FastDiv divHW, divW, divCin, divKW;
 };
 int icamd_wgrad_launch(WgradParams& p, hipStream_t stream);

@@ -86,6 +86,97 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
   shift_out[c] = beta[c] - running_mean[c] * sc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-launch reduce + finalize: grid (ceil(C/64), nchunks) blocks reduce their chunk of partial rows to fp64,
+// publish it (agent-scope release), and the LAST block to arrive for a channel group (agent-scope acquire)
+// sums the chunk rows in index order and runs the finalize -- bitwise reproducible, one kernel boundary instead
+// of two.  counters[blockIdx.x] must be zero on entry; the last arriver resets it.
+// ------------------------------------------------------------------------------------------------
+struct BnFinalizeArgs {
+  // MODE 0 (forward statistics)
+  const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float momentum, eps;
+  float* mean_out; float* invstd_out; float* scale_out; float* shift_out;
+  // MODE 1 (backward sums)
+  float* dgamma; float* dbeta; float* c1_out; float* c2_out; int accumulate;
+  double count;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ part, double* __restrict__ chunks,
+                                                                  unsigned int* __restrict__ counters, int nrows, int C,
+                                                                  int rows_per_chunk, BnFinalizeArgs a) {
+  __shared__ double red[16][2][64];
+  __shared__ int s_last;
+  const int cc = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + cc;
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(nrows, r0 + rows_per_chunk);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int r = r0 + rl; r < r1; r += 16) {
+      s1 += (double)part[((long long)r * 2 + 0) * C + c];
+      s2 += (double)part[((long long)r * 2 + 1) * C + c];
+    }
+  }
+  red[rl][0][cc] = s1;
+  red[rl][1][cc] = s2;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][which][cc];
+    if (c < C) chunks[((long long)blockIdx.y * 2 + which) * C + c] = s;
+  }
+  // publish this block's chunk row, then take a ticket (cdna_hip_programming.md Guideline 16, counter form)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int prev = __hip_atomic_fetch_add(&counters[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (prev == gridDim.y - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&counters[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64 || c >= C) return;
+  const int nchunks = gridDim.y;
+  double t1 = 0.0, t2 = 0.0;
+  for (int k = 0; k < nchunks; ++k) {
+    t1 += chunks[((long long)k * 2 + 0) * C + c];
+    t2 += chunks[((long long)k * 2 + 1) * C + c];
+  }
+  if constexpr (MODE == 0) {
+    const double mean = t1 / a.count;
+    double var = t2 / a.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)mean;
+    a.mean_out[c] = meanf;
+    a.invstd_out[c] = invstd;
+    const float sc = a.gamma[c] * invstd;
+    a.scale_out[c] = sc;
+    a.shift_out[c] = a.beta[c] - meanf * sc;
+    if (a.running_mean != nullptr) {
+      const double unbiased = a.count > 1.0 ? var * (a.count / (a.count - 1.0)) : var;
+      a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * meanf;
+      a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+  } else {
+    a.c1_out[c] = (float)(t1 / a.count);
+    a.c2_out[c] = (float)(t2 / a.count);
+    if (a.accumulate) { a.dgamma[c] += (float)t2; a.dbeta[c] += (float)t1; }
+    else { a.dgamma[c] = (float)t2; a.dbeta[c] = (float)t1; }
+  }
+}
+
 // out = act(y*scale[c] + shift[c] (+ residual)); 8 channels per thread
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bf16_t* __restrict__ residual,
@@ -466,14 +557,28 @@ int icamd_partials_to_chunks(const float* part, int nrows, int C, double* chunks
   return icamd_launch_status();
 }
 
+static void chunking(int nrows, int* rows_per_chunk, int* nchunks) {
+  int rpc = 128;
+  int nc = (nrows + rpc - 1) / rpc;
+  if (nc > 64) { rpc = (nrows + 63) / 64; nc = (nrows + rpc - 1) / rpc; }
+  *rows_per_chunk = rpc; *nchunks = nc;
+}
+
+// workspace head: 256 B of zero-initialised uint32 arrival counters (one per 64-channel group, C <= 4096) at a FIXED
+// offset (so no other layer's data can ever land on them), then the [64][2][C] fp64 chunk rows
+static unsigned int* counters_of(double* chunks, int C) { (void)C; return (unsigned int*)((char*)chunks - 256); }
+
 int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, float* mean,
                              float* invstd, float* scale, float* shift, double* chunks, hipStream_t s) {
-  int nchunks = 0;
-  int rc = icamd_partials_to_chunks(part, nrows, C, chunks, &nchunks, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, chunks, nchunks, C, count,
-                     gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  int rpc, nc;
+  chunking(nrows, &rpc, &nc);
+  BnFinalizeArgs a = {};
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.momentum = momentum; a.eps = eps; a.mean_out = mean; a.invstd_out = invstd; a.scale_out = scale; a.shift_out = shift;
+  a.count = count;
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel<0>, dim3((unsigned)((C + 63) / 64), (unsigned)nc), dim3(1024), 0, s, part,
+                     chunks, counters_of(chunks, C), nrows, C, rpc, a);
   return icamd_launch_status();
 }
 
@@ -519,15 +624,18 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
                      part, rows, C, rpb, relu);
   int rc = icamd_launch_status();
   if (rc) return rc;
-  int nchunks = 0;
-  rc = icamd_partials_to_chunks(part, nblk, C, chunks, &nchunks, s);
-  if (rc) return rc;
   float* c1 = c1c2;
   float* c2 = c1c2 + C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, chunks, nchunks, C,
-                     (double)rows, dgamma, dbeta, c1, c2, accumulate);
-  rc = icamd_launch_status();
-  if (rc) return rc;
+  {
+    int rpc, nc;
+    chunking(nblk, &rpc, &nc);
+    BnFinalizeArgs a = {};
+    a.dgamma = dgamma; a.dbeta = dbeta; a.c1_out = c1; a.c2_out = c2; a.accumulate = accumulate; a.count = (double)rows;
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)((C + 63) / 64), (unsigned)nc), dim3(1024), 0, s, part,
+                       chunks, counters_of(chunks, C), nblk, C, rpc, a);
+    rc = icamd_launch_status();
+    if (rc) return rc;
+  }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, act, y, mean, invstd,
                      scale, shift, c1, c2, dy, gout, nvec, C / 8, relu);
@@ -539,15 +647,19 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
                               const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
                               long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s) {
-  int nchunks = 0;
-  int rc = icamd_partials_to_chunks(part, nrows, C, chunks, &nchunks, s);
-  if (rc) return rc;
   float* c1 = c1c2;
   float* c2 = c1c2 + C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, chunks, nchunks, C,
-                     (double)rows, dgamma, dbeta, c1, c2, accumulate);
-  rc = icamd_launch_status();
-  if (rc) return rc;
+  int rc;
+  {
+    int rpc, nc;
+    chunking(nrows, &rpc, &nc);
+    BnFinalizeArgs a = {};
+    a.dgamma = dgamma; a.dbeta = dbeta; a.c1_out = c1; a.c2_out = c2; a.accumulate = accumulate; a.count = (double)rows;
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)((C + 63) / 64), (unsigned)nc), dim3(1024), 0, s, part,
+                       chunks, counters_of(chunks, C), nrows, C, rpc, a);
+    rc = icamd_launch_status();
+    if (rc) return rc;
+  }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, g, (const bf16_t*)nullptr, y,
                      mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, nvec, C / 8, 0);

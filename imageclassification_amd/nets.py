@@ -395,13 +395,13 @@ class ResNet:
         dfc = self.fc.desc(N, 1, 1)
         max_wg = max(max_wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(dfc)))
         ws["stats"] = torch.empty(max_stats, dtype=torch.float32, device=dev)
-        ws["bn_ws"] = torch.empty(lib.icamd_bn_workspace_bytes(2048), dtype=torch.uint8, device=dev)
+        ws["bn_ws"] = torch.zeros(lib.icamd_bn_workspace_bytes(2048), dtype=torch.uint8, device=dev)
         ws["wgrad_ws"] = torch.empty(max_wg, dtype=torch.uint8, device=dev)
         ws["wgrad_ws_bytes"] = max_wg
         ws["bnb_part"] = torch.empty(max_stats + 4 * 2 * 2048, dtype=torch.float32, device=dev)
         ws["bna_ws_bytes"] = lib.icamd_bn_bwd_apply_workspace_bytes(2048)
-        ws["bna_ws"] = torch.empty(ws["bna_ws_bytes"], dtype=torch.uint8, device=dev)
-        ws["bnb_ws"] = torch.empty(max_bnb, dtype=torch.uint8, device=dev)
+        ws["bna_ws"] = torch.zeros(ws["bna_ws_bytes"], dtype=torch.uint8, device=dev)
+        ws["bnb_ws"] = torch.zeros(max_bnb, dtype=torch.uint8, device=dev)
         ws["bnb_ws_bytes"] = max_bnb
         ws["max_act"] = max_act
         # loss / metric scratch

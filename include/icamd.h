@@ -11,7 +11,9 @@
  *     filters handed to the conv kernels are bf16 [Cout][KH][KW][Cin] ("shadow" copies the optimizer emits);
  *   - `stream` is a hipStream_t passed as void*; functions only enqueue work: they never allocate,
  *     never synchronise, never throw.  Return 0 on success, ICAMD_ERR_* otherwise;
- *   - workspaces are caller-owned; sizes come from the *_workspace_bytes queries;
+ *   - workspaces are caller-owned; sizes come from the *_workspace_bytes queries; the BatchNorm workspaces hold
+ *     arrival counters of a one-launch reduce+finalize and must be ZERO-FILLED once after allocation (the kernels
+ *     leave them zeroed again);
  *   - all floating-point reductions are order-fixed (no float atomics): results are bitwise reproducible.
  */
 #ifndef ICAMD_H

@@ -206,7 +206,7 @@ def test_bn_train_apply_and_bwd(lib, shape):
     rv0 = torch.rand(C, generator=g) + 0.5
     gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm0.clone().to(DEV), rv0.clone().to(DEV)
     mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
-    ws = torch.empty(lib.icamd_bn_workspace_bytes(C), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(lib.icamd_bn_workspace_bytes(C), dtype=torch.uint8, device=DEV)   # arrival counters start at zero
     cnt = N * H * W
     assert lib.icamd_bn_train_finalize(hip.ptr(stats), rows, C, float(cnt), hip.ptr(gd), hip.ptr(bd), hip.ptr(rmd),
                                        hip.ptr(rvd), 0.1, 1e-5, hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale),
@@ -239,7 +239,7 @@ def test_bn_train_apply_and_bwd(lib, shape):
         dout = rnd_bf16(N, H, W, C, seed=15)
         doutd = to_dev_bf16(dout)
         wsb = lib.icamd_bn_bwd_workspace_bytes(cnt, C)
-        bws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        bws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
         dgam = torch.zeros(C, device=DEV); dbet = torch.zeros(C, device=DEV)
         dy = torch.empty_like(y); gout = torch.empty_like(y)
         for recompute in ((False, True) if (relu and not use_res) else (False,)):
@@ -482,7 +482,7 @@ def test_conv_dgrad_with_fused_bn_backward(lib, case, mask_mode):
     assert lib.icamd_conv2d_dgrad_bnbwd(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(gout), hip.ptr(addd),
                                         ctypes.byref(f), hip.stream_ptr()) == 0
     wsb = lib.icamd_bn_bwd_apply_workspace_bytes(Cin)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
     dgam, dbet = torch.zeros(Cin, device=DEV), torch.zeros(Cin, device=DEV)
     dyo = torch.empty_like(gout)
     assert lib.icamd_bn_bwd_from_partials(hip.ptr(part), rows, hip.ptr(gout), hip.ptr(ybnd), hip.ptr(md), hip.ptr(isd),

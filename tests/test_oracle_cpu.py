@@ -161,7 +161,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     import ctypes
     assert lib.icamd_conv2d_stats_rows(ctypes.byref(d)) == 256 * 56 * 56 // 128
     assert lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d)) > 0
-    assert lib.icamd_bn_workspace_bytes(64) == 64 * 2 * 64 * 8
+    assert lib.icamd_bn_workspace_bytes(64) >= 64 * 2 * 64 * 8 + 4
 
 
 def test_product_fails_loudly_without_gpu():
