@@ -13,6 +13,7 @@
 // second kernel sums the S slabs in a fixed order (bitwise reproducible, no float atomics).
 #include "common.h"
 #include "icamd_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -235,11 +236,18 @@ int launch(const WgradParams& p, hipStream_t stream) {
 static inline int wgrad_tile(int n) { return n <= 64 ? 64 : 128; }
 
 void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split) {
+  // Split of the pixel reduction: each workgroup should run ~64 stages (4096 pixels) -- long enough to amortise its
+  // prologue and its fp32 slab tile, short enough to balance -- while the grid stays within [512, 2048] workgroups
+  // (2-8 per CU).  Measured on MI355X over the ResNet-50 shapes (profiles/r01 notes).
+  static const int rows_target = []() { const char* e = getenv("ICAMD_WGRAD_ROWS"); return e ? atoi(e) : 4096; }();
   const int bmk = wgrad_tile(Ktot), bnc = wgrad_tile(Cout);
   const int tiles = ((Ktot + bmk - 1) / bmk) * ((Cout + bnc - 1) / bnc);
-  int s = (1024 + tiles - 1) / tiles;
-  const int smax = (M + 511) / 512;
+  int s = (M + rows_target - 1) / rows_target;
+  const int smin = (512 + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
+  if (s < smin) s = smin;
   if (s > smax) s = smax;
+  const int scap = (M + BKR - 1) / BKR;
+  if (s > scap) s = scap;
   if (s < 1) s = 1;
   int rows = (M + s - 1) / s;
   rows = (rows + BKR - 1) / BKR * BKR;
