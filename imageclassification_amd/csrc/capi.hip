@@ -12,12 +12,12 @@ int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, 
 int icamd_bn_eval_coeffs_launch(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                 float* scale, float* shift, hipStream_t s);
 int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shift, const bf16_t* residual, bf16_t* out,
-                          long long numel, int C, int relu, hipStream_t s);
+                          unsigned char* maskbits, long long numel, int C, int relu, hipStream_t s);
 int icamd_bn_bwd_rows_per_block(long long rows, int C);
 int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
-                        long long rows, int C, int relu, int accumulate, float* part, double* chunks, float* c1c2,
-                        hipStream_t s);
+                        const unsigned char* maskbits, long long rows, int C, int relu, int accumulate, float* part,
+                        double* chunks, float* c1c2, hipStream_t s);
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
                               const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
                               long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s);
@@ -139,7 +139,7 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
 }
 
 static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
-                      const icamd_bn_bwd_fuse* f, void* stream) {
+                      const uint8_t* addend_bits, const icamd_bn_bwd_fuse* f, void* stream) {
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
   if (d->Cout % 64 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
@@ -155,6 +155,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
       memset(&p, 0, sizeof(p));
       p.in = (const bf16_t*)dy; p.wt = (const bf16_t*)w_t; p.out = (bf16_t*)dx;
       p.addend = (const bf16_t*)addend;
+      p.addend_bits = addend_bits;
       p.N = d->N; p.IH = d->OH; p.IW = d->OW; p.Cin = d->Cout;
       p.OH = d->IH; p.OW = d->IW; p.Cout = d->Cin;
       p.P = P; p.Q = Q; p.M = d->N * P * Q;
@@ -187,9 +188,10 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
 }
 
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
-                       void* stream) {
+                       const uint8_t* addend_maskbits, void* stream) {
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
-  return dgrad_impl(d, dy, w_t, dx, addend, nullptr, stream);
+  if (addend_maskbits != nullptr && (addend == nullptr || d == nullptr || d->Cin % 64 != 0)) return ICAMD_ERR_BAD_ARG;
+  return dgrad_impl(d, dy, w_t, dx, addend, addend_maskbits, nullptr, stream);
 }
 
 int icamd_conv2d_dgrad_stats_rows(const icamd_conv_desc* d) {
@@ -208,7 +210,7 @@ int icamd_conv2d_dgrad_bnbwd(const icamd_conv_desc* d, const void* dy, const voi
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
   if (f == nullptr || f->y == nullptr || f->mean == nullptr || f->invstd == nullptr || f->partials == nullptr)
     return ICAMD_ERR_BAD_ARG;
-  return dgrad_impl(d, dy, w_t, g, addend, f, stream);
+  return dgrad_impl(d, dy, w_t, g, addend, nullptr, f, stream);
 }
 
 size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
@@ -273,11 +275,11 @@ int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const flo
 }
 
 int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
-                   long long numel, int C, int relu, void* stream) {
+                   uint8_t* maskbits, long long numel, int C, int relu, void* stream) {
   ProfScope _prof(PC_BN_APPLY, stream);
   if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || numel <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
-  return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)residual, (bf16_t*)out, numel, C, relu,
-                               (hipStream_t)stream);
+  return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)residual, (bf16_t*)out, maskbits, numel, C,
+                               relu, (hipStream_t)stream);
 }
 
 // bwd workspace: partial rows [nblk][2][C] floats | chunks [64][2][C] doubles | c1,c2 [2][C] floats
@@ -290,7 +292,8 @@ size_t icamd_bn_bwd_workspace_bytes(long long rows, int C) {
 
 int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
                  const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
-                 long long rows, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                 const uint8_t* maskbits, long long rows, int C, int relu, int accumulate, void* workspace,
+                 size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
   if (dout == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr ||
       dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 || C <= 0)
@@ -307,7 +310,7 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
   ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
   float* c1c2 = (float*)ws;
   return icamd_bn_bwd_launch((const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, mean, invstd, scale, shift, dgamma,
-                             dbeta, (bf16_t*)dy, (bf16_t*)gout, rows, C, relu, accumulate, part, chunks, c1c2,
+                             dbeta, (bf16_t*)dy, (bf16_t*)gout, maskbits, rows, C, relu, accumulate, part, chunks, c1c2,
                              (hipStream_t)stream);
 }
 

@@ -244,6 +244,18 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         moff[i] = ((n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w) * p.Cout;
       }
     }
+    // ReLU-mask bits of the addend: the wave's BN/2 channels of one pixel are BN/16 consecutive bytes -> one load per row
+    unsigned long long abw[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    if (has_addend && p.addend_bits != nullptr) {
+      const int cw0 = n0 + wn * (BN / 2);
+      const int cwc = cw0 < p.Cout ? cw0 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned char* bp = p.addend_bits + ((moff[i] + cwc) >> 3);
+        if constexpr (BN == 128) abw[i] = *(const unsigned long long*)bp;
+        else abw[i] = *(const unsigned int*)bp;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int cl = wn * (BN / 2) + j * 16 + 4 * fq;      // tile-local channel of this lane's 4 values
@@ -252,16 +264,23 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
       f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
       if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
       u32x2 av[4];
+      unsigned int ab[4] = {0xffu, 0xffu, 0xffu, 0xffu};
       if (has_addend) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) av[i] = *(const u32x2*)(p.addend + moff[i] + cgc);
+        // addend is a ReLU layer's output gradient: bit = [that output > 0]; this lane's nibble within the row word
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ab[i] = (unsigned int)(abw[i] >> (8 * (j * 2 + (fq >> 1)) + 4 * (fq & 1))) & 0xfu;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = acc[j][i] + b4;
         if (has_addend) {
           const u32x2 a = av[i];
-          v[0] += bf16_lo(a[0]); v[1] += bf16_hi(a[0]); v[2] += bf16_lo(a[1]); v[3] += bf16_hi(a[1]);
+          v[0] += (ab[i] & 1u) ? bf16_lo(a[0]) : 0.f;
+          v[1] += (ab[i] & 2u) ? bf16_hi(a[0]) : 0.f;
+          v[2] += (ab[i] & 4u) ? bf16_lo(a[1]) : 0.f;
+          v[3] += (ab[i] & 8u) ? bf16_hi(a[1]) : 0.f;
         }
         const int ml = wm * 64 + i * 16 + fr;
         u32x2 pk;

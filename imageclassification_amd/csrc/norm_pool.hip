@@ -180,7 +180,8 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
 // out = act(y*scale[c] + shift[c] (+ residual)); 8 channels per thread
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bf16_t* __restrict__ residual,
-                                                       bf16_t* __restrict__ out, long long nvec, int cpr, int relu) {
+                                                       bf16_t* __restrict__ out, unsigned char* __restrict__ maskbits,
+                                                       long long nvec, int cpr, int relu) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // the launcher makes stride a multiple of cpr, so this thread's channel group never changes
@@ -209,6 +210,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
     ((u32x4*)out)[i] = o;
+    if (maskbits != nullptr) {   // bit e = [output element e > 0]: the ReLU mask the backward pass needs, 1 bit/element
+      unsigned int bits = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bits |= (f[e] > 0.f ? 1u : 0u) << e;
+      maskbits[i] = (unsigned char)bits;
+    }
   }
 }
 
@@ -221,7 +228,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ part,
-                                                            long long rows, int C, int rows_per_block, int relu) {
+                                                            const unsigned char* __restrict__ maskbits, long long rows, int C,
+                                                            int rows_per_block, int relu) {
   __shared__ float red[256 * 16];
   const int cpr = C >> 3;                 // 8-channel groups per row
   const int tid = threadIdx.x;
@@ -251,7 +259,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
           yy[2 * e] = bf16_lo(yv[e]); yy[2 * e + 1] = bf16_hi(yv[e]);
         }
         if (relu) {
-          if (act != nullptr) {
+          if (maskbits != nullptr) {
+            const unsigned int bits = maskbits[off];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (!((bits >> e) & 1u)) g[e] = 0.f;
+          } else if (act != nullptr) {
             const u32x4 a = ((const u32x4*)act)[off];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -311,7 +324,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, bf16_t* __restrict__ dy,
-                                                           bf16_t* __restrict__ gout, long long nvec, int cpr, int relu) {
+                                                           bf16_t* __restrict__ gout, const unsigned char* __restrict__ maskbits,
+                                                           long long nvec, int cpr, int relu) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cg = (int)(i % cpr) * 8;
@@ -331,7 +345,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
       yy[2 * e] = bf16_lo(yv[e]); yy[2 * e + 1] = bf16_hi(yv[e]);
     }
     if (relu) {
-      if (act != nullptr) {
+      if (maskbits != nullptr) {
+        const unsigned int bits = maskbits[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!((bits >> e) & 1u)) g[e] = 0.f;
+      } else if (act != nullptr) {
         const u32x4 a = ((const u32x4*)act)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -596,12 +615,12 @@ static unsigned int elementwise_grid(long long nvec, int cpr) {
 }
 
 int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shift, const bf16_t* residual, bf16_t* out,
-                          long long numel, int C, int relu, hipStream_t s) {
+                          unsigned char* maskbits, long long numel, int C, int relu, hipStream_t s) {
   if (C % 8 != 0 || numel % C != 0) return ICAMD_ERR_BAD_ARG;
   const long long nvec = numel / 8;
   const int cpr = C / 8;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(elementwise_grid(nvec, cpr)), dim3(256), 0, s, y, scale, shift, residual, out,
-                     nvec, cpr, relu);
+                     maskbits, nvec, cpr, relu);
   return icamd_launch_status();
 }
 
@@ -615,13 +634,13 @@ int icamd_bn_bwd_rows_per_block(long long rows, int C) {
 
 int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
-                        long long rows, int C, int relu, int accumulate, float* part, double* chunks, float* c1c2,
-                        hipStream_t s) {
+                        const unsigned char* maskbits, long long rows, int C, int relu, int accumulate, float* part,
+                        double* chunks, float* c1c2, hipStream_t s) {
   if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
   const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
   const int nblk = (int)((rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dout, act, y, mean, invstd, scale, shift,
-                     part, rows, C, rpb, relu);
+                     part, maskbits, rows, C, rpb, relu);
   int rc = icamd_launch_status();
   if (rc) return rc;
   float* c1 = c1c2;
@@ -638,7 +657,7 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, act, y, mean, invstd,
-                     scale, shift, c1, c2, dy, gout, nvec, C / 8, relu);
+                     scale, shift, c1, c2, dy, gout, maskbits, nvec, C / 8, relu);
   return icamd_launch_status();
 }
 
@@ -662,7 +681,7 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, g, (const bf16_t*)nullptr, y,
-                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, nvec, C / 8, 0);
+                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, (const unsigned char*)nullptr, nvec, C / 8, 0);
   return icamd_launch_status();
 }
 

@@ -43,7 +43,7 @@ _SIGNATURES = {
     "icamd_abi_version": (c_int, []),
     "icamd_conv2d_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
-    "icamd_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "icamd_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "icamd_conv2d_dgrad_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, POINTER(BnBwdFuse), _P]),
     "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
@@ -52,9 +52,9 @@ _SIGNATURES = {
     "icamd_bn_workspace_bytes": (c_size_t, [c_int]),
     "icamd_bn_train_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "icamd_bn_eval_coeffs": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
-    "icamd_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
+    "icamd_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "icamd_bn_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
-    "icamd_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "icamd_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_size_t, _P]),
     "icamd_bn_bwd_apply_workspace_bytes": (c_size_t, [c_int]),
     "icamd_bn_bwd_from_partials": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
     "icamd_maxpool3x3s2_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -379,6 +379,7 @@ class ResNet:
                 max_bnb = max(max_bnb, lib.icamd_bn_bwd_workspace_bytes(N * d.OH * d.OW, conv.cout_p))
                 ih, iw = d.OH, d.OW
             b["y"], b["a"] = ys, acts
+            b["mask"] = torch.empty(acts[-1].numel() // 8, dtype=torch.uint8, device=dev)   # ReLU mask of the block output
             if "down_conv" in blk:
                 dd = blk["down_conv"].desc(N, h, w)
                 b["yd"] = act(N, dd.OH, dd.OW, blk["down_conv"].cout_p)
@@ -433,7 +434,7 @@ class ResNet:
     def _gf(self, p):  # fp32 grad pointer
         return self.grad_arena.data_ptr() + 4 * p.offset
 
-    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s):
+    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s, maskbits=None):
         """y = conv(x); out = act(bn(y) (+ residual)). Training: batch statistics from the conv epilogue."""
         lib = self.lib
         d = conv.desc(N, IH, IW)
@@ -455,8 +456,8 @@ class ResNet:
             shift = scale + 4 * 2048
             hip.check(lib.icamd_bn_eval_coeffs(c, self._pf(bn.weight), self._pf(bn.bias), rm, rm + 4 * c, BN_EPS, scale,
                                                shift, s), bn.name)
-        hip.check(lib.icamd_bn_apply(y.data_ptr(), scale, shift, residual, out.data_ptr(), y.numel(), c, int(relu), s),
-                  bn.name)
+        hip.check(lib.icamd_bn_apply(y.data_ptr(), scale, shift, residual, out.data_ptr(), maskbits, y.numel(), c, int(relu),
+                                     s), bn.name)
         return d
 
     # ------------------------------------------------------------------ forward
@@ -496,7 +497,8 @@ class ResNet:
             for i, (conv, bn) in enumerate(zip(convs, bns)):
                 last = i == len(convs) - 1
                 d = self._conv_bn_fwd(ws, conv, bn, cur.data_ptr(), N, ch, cw, b["y"][i], b["a"][i],
-                                      idn.data_ptr() if last else None, True, s)
+                                      idn.data_ptr() if last else None, True, s,
+                                      b["mask"].data_ptr() if (last and self.training) else None)
                 cur, ch, cw = b["a"][i], d.OH, d.OW
             x, h, w = cur, ch, cw
         hip.check(lib.icamd_avgpool_fwd(x.data_ptr(), ws["pooled"].data_ptr(), N, h * w, self.feat_dim, s), "avgpool")
@@ -530,18 +532,18 @@ class ResNet:
             hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, s),
                       conv.name + " wgrad")
 
-        def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw):
+        def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw, addend_bits=None):
             d = conv.desc(n, ih, iw)
-            hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, s),
+            hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, addend_bits, s),
                       conv.name + " dgrad")
 
-        def bn_bwd(bn, dout_ptr, act_ptr, y, dy_ptr, gout_ptr, relu):
+        def bn_bwd(bn, dout_ptr, act_ptr, y, dy_ptr, gout_ptr, relu, maskbits=None):
             st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
             c = bn.c
             rows = y.numel() // c
             hip.check(lib.icamd_bn_bwd(dout_ptr, act_ptr, y.data_ptr(), st, st + 4 * c, st + 8 * c, st + 12 * c,
-                                       self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, rows, c, int(relu), acc,
-                                       bws, bwb, s), bn.name + " bwd")
+                                       self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, maskbits, rows, c, int(relu),
+                                       acc, bws, bwb, s), bn.name + " bwd")
 
         # classifier
         dl = ws["dlogits"].data_ptr()
@@ -564,8 +566,10 @@ class ResNet:
             for conv in convs[:-1]:
                 d = conv.desc(N, *hw_in[-1])
                 hw_in.append((d.OH, d.OW))
-            # last BN (+ residual + ReLU): mask from the stored block output
-            bn_bwd(bns[-1], dout, b["a"][-1].data_ptr(), b["y"][-1], Y, G, True)
+            # last BN (+ residual + ReLU): g = dout * [block output > 0] via the 1-bit mask the forward stored; g itself is
+            # never written: the shortcut consumers below re-apply the same bits to `dout`
+            mask = b["mask"].data_ptr()
+            bn_bwd(bns[-1], dout, None, b["y"][-1], Y, None, True, mask)
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
                 wgrad(convs[i], x_i.data_ptr(), Y, N, *hw_in[i])
@@ -574,12 +578,12 @@ class ResNet:
                 bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], Y, None, True)
             wgrad(convs[0], xin.data_ptr(), Y, N, h, w)
             if "down_conv" in blk:
-                bn_bwd(blk["down_bn"], G, None, b["yd"], Y2, None, False)
+                bn_bwd(blk["down_bn"], dout, None, b["yd"], Y2, None, True, mask)   # "relu" = apply the block's mask bits
                 wgrad(blk["down_conv"], xin.data_ptr(), Y2, N, h, w)
                 dgrad(blk["down_conv"], Y2, T, None, N, h, w)
                 dgrad(convs[0], Y, other, T, N, h, w)
             else:
-                dgrad(convs[0], Y, other, G, N, h, w)
+                dgrad(convs[0], Y, other, dout, N, h, w, mask)
             if hook:
                 hook(convs[0].w.offset, None)
             dout, other = other, dout
@@ -613,7 +617,7 @@ class ResNet:
 
         def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw):
             d = conv.desc(n, ih, iw)
-            hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, s),
+            hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, None, s),
                       conv.name + " dgrad")
 
         def bn_bwd(bn, dout_ptr, act_ptr, y, dy_ptr, gout_ptr, relu):
@@ -621,7 +625,7 @@ class ResNet:
             c = bn.c
             rows = y.numel() // c
             hip.check(lib.icamd_bn_bwd(dout_ptr, act_ptr, y.data_ptr(), st, st + 4 * c, st + 8 * c, st + 12 * c,
-                                       self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, rows, c, int(relu), acc,
+                                       self._gf(bn.weight), self._gf(bn.bias), dy_ptr, gout_ptr, None, rows, c, int(relu), acc,
                                        bws, bwb, s), bn.name + " bwd")
 
         P, pw_bytes = ws["bnb_part"].data_ptr(), ws["bna_ws_bytes"]

@@ -51,9 +51,11 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
                      const void* addend, float* stats, void* stream);
 
 /* dx = conv_transpose(dy, w) (+ addend shaped like dx).  w_t is the [Cin][KH][KW][Cout] transposed bf16 filter
- * (icamd_filter_transpose).  Requires Cout % 64 == 0. */
+ * (icamd_filter_transpose).  Requires Cout % 64 == 0.  addend_maskbits (optional, 1 bit per addend element, as
+ * written by icamd_bn_apply): the addend is counted only where its bit is set -- lets the residual branch add
+ * "output gradient x ReLU mask" without that product ever being materialised. */
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
-                       void* stream);
+                       const uint8_t* addend_maskbits, void* stream);
 
 /* Data gradient with the NEXT BatchNorm backward's first pass fused into the epilogue: the tensor this call produces
  * is the output-gradient of a BatchNorm(+residual)+ReLU layer, so the kernel applies that layer's ReLU mask
@@ -92,15 +94,17 @@ int icamd_bn_train_finalize(const float* partials, int nrows, int C, double coun
                             float* mean, float* invstd, float* scale, float* shift, void* workspace, void* stream);
 int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, void* stream);
-/* out = act(y*scale[c] + shift[c] (+ residual)), act = ReLU if relu else identity */
+/* out = act(y*scale[c] + shift[c] (+ residual)), act = ReLU if relu else identity.
+ * maskbits (optional, numel/8 bytes): bit k of byte i <- [out[8i+k] > 0], the ReLU mask for the backward pass. */
 int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
-                   long long numel, int C, int relu, void* stream);
+                   uint8_t* maskbits, long long numel, int C, int relu, void* stream);
 size_t icamd_bn_bwd_workspace_bytes(long long rows, int C);
-/* g = dout * [act > 0] (act == NULL with relu: mask recomputed from y*scale+shift > 0);
+/* g = dout * mask, mask (when relu) = maskbits if given, else [act > 0] if act given, else [y*scale+shift > 0];
  * dgamma = sum g*xhat, dbeta = sum g, dy = scale*(g - mean(g) - xhat*mean(g*xhat)); gout (optional) <- g */
 int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* mean, const float* invstd,
                  const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
-                 long long rows, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                 const uint8_t* maskbits, long long rows, int C, int relu, int accumulate, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* second half of the fused form: finalize (dgamma, dbeta, means) + dy = scale*(g - mean(g) - xhat*mean(g*xhat)) */
 size_t icamd_bn_bwd_apply_workspace_bytes(int C);

@@ -114,7 +114,7 @@ def test_conv_dgrad(lib, case):
         ad = to_dev_bf16(addend) if use_add else None
         dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w_t)   # keep alive: a temporary's block would be reused
         rc = lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx),
-                                    hip.ptr(ad), hip.stream_ptr())
+                                    hip.ptr(ad), None, hip.stream_ptr())
         assert rc == 0
         sync()
         got = dx.float().cpu()
@@ -229,12 +229,16 @@ def test_bn_train_apply_and_bwd(lib, shape):
     resd = to_dev_bf16(res)
     for use_res, relu in ((False, True), (True, True), (False, False)):
         out = torch.empty_like(y)
+        bits = torch.zeros(y.numel() // 8, dtype=torch.uint8, device=DEV)
         assert lib.icamd_bn_apply(hip.ptr(y), hip.ptr(scale), hip.ptr(shift), hip.ptr(resd) if use_res else None,
-                                  hip.ptr(out), y.numel(), C, int(relu), hip.stream_ptr()) == 0
+                                  hip.ptr(out), hip.ptr(bits), y.numel(), C, int(relu), hip.stream_ptr()) == 0
         sync()
         ref = R.bn_apply(yc, scale.cpu(), shift.cpu(), res if use_res else None, relu)
         oc = out.float().cpu()
         assert R.max_bf16_ulp(oc, ref) <= 1.0 and R.rel_l2(oc, ref) <= 1e-3
+        # 1-bit ReLU mask: bit k of byte i == [out[8i+k] > 0]
+        unpacked = ((bits.cpu().view(-1, 1) >> torch.arange(8, dtype=torch.uint8)) & 1).flatten().bool()
+        assert torch.equal(unpacked, oc.flatten() > 0)
         # backward
         dout = rnd_bf16(N, H, W, C, seed=15)
         doutd = to_dev_bf16(dout)
@@ -242,10 +246,12 @@ def test_bn_train_apply_and_bwd(lib, shape):
         bws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
         dgam = torch.zeros(C, device=DEV); dbet = torch.zeros(C, device=DEV)
         dy = torch.empty_like(y); gout = torch.empty_like(y)
-        for recompute in ((False, True) if (relu and not use_res) else (False,)):
-            actp = None if recompute else hip.ptr(out)
+        modes = ("act", "bits") + (("recompute",) if (relu and not use_res) else ())
+        for mode in modes:
+            actp = hip.ptr(out) if mode == "act" else None
+            bitp = hip.ptr(bits) if mode == "bits" else None
             assert lib.icamd_bn_bwd(hip.ptr(doutd), actp, hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale),
-                                    hip.ptr(shift), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(dy), hip.ptr(gout), cnt, C,
+                                    hip.ptr(shift), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(dy), hip.ptr(gout), bitp, cnt, C,
                                     int(relu), 0, hip.ptr(bws), wsb, hip.stream_ptr()) == 0
             sync()
             rdy, rdg, rdb, rg = R.bn_bwd(dout, oc, yc, mean.cpu(), invstd.cpu(), scale.cpu(), relu)
@@ -498,3 +504,25 @@ def test_conv_dgrad_with_fused_bn_backward(lib, case, mask_mode):
     assert R.rel_l2(dgam.cpu(), rdg) <= 5e-3 and R.rel_l2(dbet.cpu(), rdb) <= 5e-3
     got = dyo.float().cpu()
     assert R.rel_l2(got, rdy) <= 2e-3 and R.bf16_close(got, rdy, ulps=2.0, atol_rms=4e-3)
+
+
+def test_conv_dgrad_addend_maskbits(lib):
+    """dx = dgrad(dy) + addend * [bit]: the residual shortcut adds the masked output gradient without materialising it."""
+    hip = _hip()
+    N, H, W, Cin, Cout, k, st, pad = 2, 10, 9, 128, 64, 1, 1, 0
+    d = hip.conv_desc(N, H, W, Cin, Cout, k, k, st, pad)
+    dy = rnd_bf16(N, d.OH, d.OW, Cout, seed=90)
+    w = rnd_bf16(Cout, k, k, Cin, scale=0.1, seed=91)
+    addend = rnd_bf16(N, H, W, Cin, seed=92)
+    mask = torch.rand(N, H, W, Cin, generator=torch.Generator().manual_seed(93)) > 0.4
+    bits = (mask.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
+    ref = R.conv2d_dgrad(dy, w, (H, W), st, pad, addend * mask)
+    dyd, wtd, ad, bd = to_dev_bf16(dy), to_dev_bf16(w.permute(3, 1, 2, 0).contiguous()), to_dev_bf16(addend), bits.to(DEV)
+    dx = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+    assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), hip.ptr(bd),
+                                  hip.stream_ptr()) == 0
+    sync()
+    got = dx.float().cpu()
+    assert R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
+    assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), None, hip.ptr(bd),
+                                  hip.stream_ptr()) == 1      # bits without an addend: bad argument

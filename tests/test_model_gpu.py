@@ -136,6 +136,10 @@ def test_backward_teacher_forced_is_tight(arch, B, HW, tol):
             b["y"][i].copy_(_nhwc(tr[f"{n}.{i}.y"]))
             b["a"][i].copy_(_nhwc(tr[f"{n}.{i}.a"]))
             put_stats(bn, tr[f"{n}.{i}.y"])
+        # the backward reads the block-output ReLU mask as 1 bit per element: rebuild it from the oracle activation
+        last = _nhwc(tr[f"{n}.{len(blk['bns']) - 1}.a"]).float() > 0
+        packed = (last.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
+        b["mask"].copy_(packed.cuda())
         if "down_conv" in blk:
             b["yd"].copy_(_nhwc(tr[f"{n}.down.y"]))
             b["ad"].copy_(_nhwc(tr[f"{n}.down.a"]))

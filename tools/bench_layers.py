@@ -52,7 +52,7 @@ def main():
         t_f = timeit(lambda: hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, stats.data_ptr(), s)))
         t_d = float("nan")
         if cin != 8:
-            t_d = timeit(lambda: hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, s)))
+            t_d = timeit(lambda: hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, s)))
         t_df = float("nan")
         if cin != 8:
             ybn = torch.randn(N, h, h, cin, device="cuda").to(torch.bfloat16)

@@ -19,7 +19,7 @@ rows = lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d))
 part = torch.empty(rows * 2 * cin, device="cuda")
 f = hip.BnBwdFuse(ybn.data_ptr(), None, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), part.data_ptr(), 1)
 for _ in range(reps):
-    hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, s))
+    hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, None, s))
 for _ in range(reps):
     hip.check(lib.icamd_conv2d_dgrad_bnbwd(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), None, ctypes.byref(f), s))
 torch.cuda.synchronize()
