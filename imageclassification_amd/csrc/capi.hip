@@ -45,6 +45,8 @@ int icamd_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, hipStre
 int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
                                   int njobs, hipStream_t s);
 int icamd_colsum_launch(const bf16_t* x, int rows, int ld, int cols, float* out, int accumulate, hipStream_t s);
+int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
+                                        int njobs, hipStream_t s);
 
 
 // ---- optional in-process kernel timing (HIP events on the launch stream), used by bench.py ------------------
@@ -247,6 +249,14 @@ int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* 
   if (src_base == nullptr || dst_base == nullptr || descs == nullptr || jobs == nullptr || njobs < 0) return ICAMD_ERR_BAD_ARG;
   return icamd_filter_transpose_launch((const bf16_t*)src_base, (bf16_t*)dst_base, (const long long*)descs, jobs, njobs,
                                        (hipStream_t)stream);
+}
+
+int icamd_filter_transpose_tiled(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
+                                 void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
+  if (src_base == nullptr || dst_base == nullptr || descs == nullptr || jobs == nullptr || njobs < 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_filter_transpose_tiled_launch((const bf16_t*)src_base, (bf16_t*)dst_base, (const long long*)descs, jobs, njobs,
+                                             (hipStream_t)stream);
 }
 
 // BN workspace: [64 chunks][2][C] doubles

@@ -54,10 +54,17 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wc = wave >> 1;
 
-  unsigned int b = blockIdx.x;
-  const int split = b % p.S; b /= p.S;
-  const int tile_c = b % p.ntiles_c;
-  const int tile_k = b / p.ntiles_c;
+  // Block order: 8 consecutive pixel splits form a group; inside a group block ids go tile-major with the split as the
+  // low 3 bits, so (blocks b and b+8 share an XCD) all output tiles of one split run on ONE XCD at about the same time and
+  // the split's dY / X pixels are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
+  const unsigned int nt = (unsigned)(p.ntiles_k * p.ntiles_c);
+  const unsigned int grp = blockIdx.x / (8u * nt);
+  const unsigned int rem = blockIdx.x - grp * 8u * nt;
+  const unsigned int ns = min(8u, (unsigned)p.S - grp * 8u);
+  const unsigned int tile = rem / ns;
+  const int split = (int)(grp * 8u + (rem - tile * ns));
+  const int tile_c = (int)(tile % (unsigned)p.ntiles_c);
+  const int tile_k = (int)(tile / (unsigned)p.ntiles_c);
   const int k0 = tile_k * BMK, c0 = tile_c * BNC;
   const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);

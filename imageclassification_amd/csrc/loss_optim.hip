@@ -277,6 +277,39 @@ __global__ __launch_bounds__(256) void filter_transpose_kernel(const bf16_t* __r
   }
 }
 
+// Tiled variant for layers with Cout % 64 == 0 and Cin % 64 == 0 (every ResNet filter but the stem): one workgroup
+// moves a 64(co) x 64(ci) tile of one tap through LDS so that both the reads and the writes are 128 B row segments.
+// jobs: int32[njobs][4] = {layer, tap, co0, ci0}
+__global__ __launch_bounds__(256) void filter_transpose_tiled_kernel(const bf16_t* __restrict__ src_base,
+                                                                     bf16_t* __restrict__ dst_base,
+                                                                     const long long* __restrict__ descs,
+                                                                     const int* __restrict__ jobs) {
+  __shared__ bf16_t tile[64][72];   // [co][ci], rows padded to 144 B
+  const int* job = jobs + blockIdx.x * 4;
+  const long long* d = descs + (long long)job[0] * 8;
+  const int t = job[1], co0 = job[2], ci0 = job[3];
+  const int Cout = (int)d[2], T = (int)d[3], Cin = (int)d[4];
+  const bf16_t* src = src_base + d[0];
+  bf16_t* dst = dst_base + d[1];
+  const int r = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int co = r + pass * 32;
+    const u32x4 v = *(const u32x4*)(src + ((long long)(co0 + co) * T + t) * Cin + ci0 + c8);
+    *(u32x4*)&tile[co][c8] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int ci = r + pass * 32;
+    unsigned int w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w[e] = (unsigned int)tile[c8 + 2 * e][ci] | ((unsigned int)tile[c8 + 2 * e + 1][ci] << 16);
+    *(u32x4*)(dst + ((long long)(ci0 + ci) * T + t) * Cout + co0 + c8) = u32x4{w[0], w[1], w[2], w[3]};
+  }
+}
+
 // column sums of a bf16 matrix [rows][ld] -> fp32 [cols] (FC bias gradient); one thread per column
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int rows, int ld, int cols,
                                                      float* __restrict__ out, int accumulate) {
@@ -351,6 +384,13 @@ int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, cons
                                   int njobs, hipStream_t s) {
   if (njobs <= 0) return ICAMD_OK;
   hipLaunchKernelGGL(filter_transpose_kernel, dim3((unsigned)njobs), dim3(256), 0, s, src_base, dst_base, descs, jobs);
+  return icamd_launch_status();
+}
+
+int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
+                                        int njobs, hipStream_t s) {
+  if (njobs <= 0) return ICAMD_OK;
+  hipLaunchKernelGGL(filter_transpose_tiled_kernel, dim3((unsigned)njobs), dim3(256), 0, s, src_base, dst_base, descs, jobs);
   return icamd_launch_status();
 }
 

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "icamd_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_size_t, _P]),
     "icamd_filter_transpose": (c_int, [_P, _P, _P, _P, c_int, _P]),
+    "icamd_filter_transpose_tiled": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "icamd_bn_workspace_bytes": (c_size_t, [c_int]),
     "icamd_bn_train_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "icamd_bn_eval_coeffs": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),

@@ -187,20 +187,28 @@ class ResNet:
         self.stat_arena = torch.zeros(max(soff, 64), dtype=torch.float32, device=dev)
         # transposed filters for the data-gradient kernels (every conv except the stem)
         toff = 0
-        descs, jobs = [], []
+        descs, jobs, tjobs = [], [], []
         for m in self.convs:
             if m is self.stem_conv:
                 continue
             m.wt_offset = toff
             T = m.k * m.k
             descs.append([m.w.offset, toff, m.cout_p, T, m.cin_p, 0, 0, 0])
-            for s in range(0, m.w.numel, 4096):
-                jobs.append([len(descs) - 1, s])
+            if m.cout_p % 64 == 0 and m.cin_p % 64 == 0:
+                for t in range(T):
+                    for co0 in range(0, m.cout_p, 64):
+                        for ci0 in range(0, m.cin_p, 64):
+                            tjobs.append([len(descs) - 1, t, co0, ci0])
+            else:
+                for s in range(0, m.w.numel, 4096):
+                    jobs.append([len(descs) - 1, s])
             toff = _align(toff + m.w.numel, 128)
         self.shadow_t = torch.zeros(toff, dtype=torch.bfloat16, device=dev)
         self._tr_descs = torch.tensor(descs, dtype=torch.int64, device=dev)
-        self._tr_jobs = torch.tensor(jobs, dtype=torch.int32, device=dev)
+        self._tr_jobs = torch.tensor(jobs if jobs else [[0, 0]], dtype=torch.int32, device=dev)
         self._tr_njobs = len(jobs)
+        self._tr_tjobs = torch.tensor(tjobs if tjobs else [[0, 0, 0, 0]], dtype=torch.int32, device=dev)
+        self._tr_ntjobs = len(tjobs)
 
     # ------------------------------------------------------------------ parameters / state_dict
     def init_weights(self, zero_init_last=True, seed=None):
@@ -325,9 +333,15 @@ class ResNet:
         self.refresh_transposed()
 
     def refresh_transposed(self):
-        hip.check(self.lib.icamd_filter_transpose(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
-                                                  self._tr_descs.data_ptr(), self._tr_jobs.data_ptr(), self._tr_njobs,
-                                                  hip.stream_ptr()), "filter_transpose")
+        s = hip.stream_ptr()
+        if self._tr_ntjobs:
+            hip.check(self.lib.icamd_filter_transpose_tiled(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
+                                                            self._tr_descs.data_ptr(), self._tr_tjobs.data_ptr(),
+                                                            self._tr_ntjobs, s), "filter_transpose_tiled")
+        if self._tr_njobs:
+            hip.check(self.lib.icamd_filter_transpose(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
+                                                      self._tr_descs.data_ptr(), self._tr_jobs.data_ptr(), self._tr_njobs,
+                                                      s), "filter_transpose")
 
     def train(self, mode=True):
         self.training = bool(mode)

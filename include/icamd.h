@@ -83,6 +83,10 @@ int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, 
  * jobs: int32[njobs][2] = {layer, first destination element}, each job covers 4096 destination elements. */
 int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
                            void* stream);
+/* same, for layers with Cout % 64 == 0 and Cin % 64 == 0, 64x64 tiles through LDS (coalesced both ways);
+ * jobs: int32[njobs][4] = {layer, tap, co0, ci0}, co0 and ci0 multiples of 64. */
+int icamd_filter_transpose_tiled(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs,
+                                 int njobs, void* stream);
 
 /* ---- BatchNorm / ReLU / residual (timm BatchNorm2d + ReLU layers under the same reference calls) -------- */
 size_t icamd_bn_workspace_bytes(int C);

@@ -182,6 +182,23 @@ def test_filter_transpose(lib):
         n = p.numel()
         assert torch.equal(got[off:off + n].reshape(p.shape[2], p.shape[1], p.shape[0]), p.permute(2, 1, 0))
         off += n
+    # tiled variant on the layers whose channel counts are multiples of 64
+    tj = []
+    for li, (co, tt, ci) in enumerate(shapes):
+        if co % 64 == 0 and ci % 64 == 0:
+            tj += [[li, t_, a, b] for t_ in range(tt) for a in range(0, co, 64) for b in range(0, ci, 64)]
+    dst2 = torch.zeros_like(srcd)
+    tjd = torch.tensor(tj, dtype=torch.int32, device=DEV)
+    assert lib.icamd_filter_transpose_tiled(hip.ptr(srcd), hip.ptr(dst2), hip.ptr(descd), hip.ptr(tjd), len(tj),
+                                            hip.stream_ptr()) == 0
+    sync()
+    got2 = dst2.float().cpu()
+    off = 0
+    for (co, tt, ci), p in zip(shapes, src_parts):
+        n = p.numel()
+        if co % 64 == 0 and ci % 64 == 0:
+            assert torch.equal(got2[off:off + n].reshape(ci, tt, co), p.permute(2, 1, 0))
+        off += n
 
 
 @pytest.mark.parametrize("shape", [(4, 6, 6, 64), (2, 5, 5, 2048), (8, 20, 20, 128), (3, 7, 7, 96)])
