@@ -7,6 +7,7 @@
 // `model(samples)` and `loss.backward()` in /root/reference/engine.py:48,51,64,72.
 #include "common.h"
 #include "icamd_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -553,8 +554,9 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 }
 
 inline unsigned int grid_for(long long work_items, int threads, int multiple_of) {
+  static const long long cap = []() { const char* e = getenv("ICAMD_EW_BLOCKS"); return e ? atoll(e) : 1024ll; }();
   long long blocks = (work_items + threads - 1) / threads;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   if (multiple_of > 1) blocks = (blocks + multiple_of - 1) / multiple_of * multiple_of;
   return (unsigned int)blocks;
@@ -625,8 +627,9 @@ int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shif
 }
 
 int icamd_bn_bwd_rows_per_block(long long rows, int C) {
-  // aim for ~2048 blocks, at least 32 rows each
-  long long rpb = (rows + 2047) / 2048;
+  // aim for ~N blocks (default 2048), at least 32 rows each
+  static const long long nb = []() { const char* e = getenv("ICAMD_BNBWD_BLOCKS"); return e ? atoll(e) : 1024ll; }();
+  long long rpb = (rows + nb - 1) / nb;
   if (rpb < 32) rpb = 32;
   (void)C;
   return (int)rpb;
