@@ -178,8 +178,17 @@ def main():
         dom = max(mfma_classes, key=lambda k: kern[k]["ms_per_step"])
         ach = algo[dom] / (kern[dom]["ms_per_step"] * 1e-3) / 1e12
         per_launch_flops = algo[dom] / kern[dom]["calls_per_step"]
+        traffic = None
+        try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            names = {"conv_wgrad": "conv_wgrad_kernel", "conv_fwd": "conv_igemm_kernel", "conv_dgrad": "conv_igemm_kernel"}
+            sel = [v for k, v in pmc["kernels"].items() if k.startswith(names[dom])]
+            n = sum(v["launches"] for v in sel)
+            traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in sel) / n)
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2),
                     "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
         for k in mfma_classes:
