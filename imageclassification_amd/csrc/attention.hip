@@ -1,0 +1,360 @@
+// Multi-head self-attention for short sequences (ViT: T = 197, head dim 64) on gfx950: forward and backward, one
+// workgroup (4 wavefronts) per (image, head), everything of that head resident in LDS, bf16 operands, fp32 MFMA
+// accumulation (v_mfma_f32_16x16x32_bf16), softmax in registers.
+//
+// Replaces what ATen runs for timm's Attention module (softmax(q k^T / sqrt(d)) v) under `model(samples)` and
+// `loss.backward()` of the reference step (/root/reference/engine.py:48,51,64,72) for vit_base_patch16_224.
+//
+// Layout: qkv is the [B*T][3*H*64] output of the fused QKV projection (columns q | k | v, each [head][64]);
+// out / dout are [B*T][H*64]; dqkv mirrors qkv; lse and delta are fp32 [B][H][T].
+//
+// The score tile is always computed TRANSPOSED relative to the operand that will consume it, so that an accumulator
+// tile is directly the next MFMA's operand (k order permuted identically on both operands) and nothing ever crosses
+// LDS between two products:
+//   forward        : S^T = K Q^T (query on the lane) -> softmax per lane column -> O = P V with P straight from the
+//                    accumulators and V^T fragments by ds_read_b64_tr_b16;
+//   backward (dQ)  : S^T, dP^T = V dO^T (query on the lane) -> dS^T -> dQ^T = K^T dS^T (K^T by transposed reads);
+//   backward (dK,dV): S = Q K^T, dP = dO V^T (key on the lane) -> dV^T = dO^T P, dK^T = Q^T dS (transposed reads of
+//                    dO and Q); each wave owns whole key blocks, so no cross-wave reduction and no atomics.
+// The two backward kernels recompute S and dP independently (7 products instead of 5): attention is 4 % of ViT-B's
+// FLOPs, and this keeps every sum in a fixed order (bitwise reproducible).
+#include "common.h"
+#include "icamd_internal.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dimension
+constexpr int ROWB = HD * 2;    // bytes per LDS row
+
+// LDS images of a [rows][64] bf16 matrix (128 B rows)
+//  "row" image: read 16 B chunks of one row per lane (ds_read_b128): chunk ^= (row>>1)&7
+//  "tr"  image: read 4-row x 16-column blocks transposed (ds_read_b64_tr_b16): 32 B block ^= (row>>1)&3
+__device__ __forceinline__ int row_img(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int tr_img(int row, int chunk) {
+  return row * ROWB + ((((chunk >> 1) ^ ((row >> 1) & 3))) << 5) + ((chunk & 1) << 4);
+}
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* img, int row0, int row1, int dblk, int lane) {
+  const int c = lane & 15, q = c >> 2, pq = c & 3;
+  const int ra = row0 + q, rb = row1 + q;
+  bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (bf16x4 __attribute__((address_space(3)))*)(img + ra * ROWB + ((dblk ^ ((ra >> 1) & 3)) << 5) + 8 * pq));
+  bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (bf16x4 __attribute__((address_space(3)))*)(img + rb * ROWB + ((dblk ^ ((rb >> 1) & 3)) << 5) + 8 * pq));
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+__device__ __forceinline__ bf16x8 pack_acc2(const f32x4& lo, const f32x4& hi) {
+  bf16x8 r;
+  r[0] = (short)f32_to_bf16(lo[0]); r[1] = (short)f32_to_bf16(lo[1]); r[2] = (short)f32_to_bf16(lo[2]); r[3] = (short)f32_to_bf16(lo[3]);
+  r[4] = (short)f32_to_bf16(hi[0]); r[5] = (short)f32_to_bf16(hi[1]); r[6] = (short)f32_to_bf16(hi[2]); r[7] = (short)f32_to_bf16(hi[3]);
+  return r;
+}
+
+// stage a [T][64] slice (rows beyond T and up to `rows_pad` zero) of a token matrix into one or two LDS images
+template <bool ROWIMG, bool TRIMG>
+__device__ __forceinline__ void stage_matrix(const bf16_t* __restrict__ src, long long ld, int T, int rows_pad,
+                                             unsigned char* img_row, unsigned char* img_tr) {
+  for (int i = threadIdx.x; i < rows_pad * 8; i += 256) {
+    const int r = i >> 3, ch = i & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < T) v = *(const u32x4*)(src + (long long)r * ld + ch * 8);
+    if constexpr (ROWIMG) *(u32x4*)(img_row + row_img(r, ch)) = v;
+    if constexpr (TRIMG) *(u32x4*)(img_tr + tr_img(r, ch)) = v;
+  }
+}
+
+// B-operand fragments of a row-major [row][64] matrix straight from global memory: lane (c, g) takes row `row`,
+// columns 8g..8g+7 (+32 for the second k-step)
+__device__ __forceinline__ void load_rowfrag(const bf16_t* __restrict__ base, long long ld, int row, int T, int g,
+                                             bf16x8* f) {
+  const int rr = row < T ? row : 0;
+  const bf16_t* p = base + (long long)rr * ld + 8 * g;
+  f[0] = *(const bf16x8*)p;
+  f[1] = *(const bf16x8*)(p + 32);
+  if (row >= T) { f[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; f[1] = f[0]; }
+}
+
+__device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups that share a column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// forward
+// ----------------------------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int T, int H, float scale) {
+  constexpr int NPAIR = (NKB + 1) / 2;
+  constexpr int RP = NPAIR * 32;   // padded key rows (zeros beyond T)
+  __shared__ __attribute__((aligned(16))) unsigned char Kr[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[RP * ROWB];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long ld = 3ll * H * HD;
+  const bf16_t* base = qkv + (long long)b * T * ld;
+  const bf16_t* qb_ = base + h * HD;
+  const bf16_t* kb_ = base + (long long)H * HD + h * HD;
+  const bf16_t* vb_ = base + 2ll * H * HD + h * HD;
+  stage_matrix<true, false>(kb_, ld, T, RP, Kr, nullptr);
+  stage_matrix<false, true>(vb_, ld, T, RP, nullptr, Vt);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  for (int qblk = wave; qblk < NKB; qblk += 4) {
+    const int qrow = qblk * 16 + c;
+    bf16x8 qf[2];
+    load_rowfrag(qb_, ld, qrow, T, g, qf);
+    f32x4 s[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(Kr + row_img(kb * 16 + c, ks * 4 + g));
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);   // S^T[key][query]
+      }
+    }
+    // lane (c, g) now holds, for query c, keys kb*16 + 4g + r
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb * 16 + 4 * g + r;
+        s[kb][r] = key < T ? s[kb][r] * scale : -INFINITY;
+        m = fmaxf(m, s[kb][r]);
+      }
+    m = group_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[kb][r] = __expf(s[kb][r] - m); l += s[kb][r]; }
+    l = group_sum(l);
+    if (g == 0 && qrow < T) lse[((long long)b * H + h) * T + qrow] = m + __logf(l);
+    // O[query][d] = sum_key P[query][key] V[key][d]
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < NPAIR; ++pp) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const bf16x8 pf = pack_acc2(s[2 * pp], (2 * pp + 1 < NKB) ? s[2 * pp + 1] : zero);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 vf = tr_pair(Vt, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, db, lane);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[db], 0, 0, 0);   // D[query 4g+r][d = db*16 + c]
+      }
+    }
+    const float inv_l = 1.f / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float il = __shfl(inv_l, 4 * g + r, 64);   // 1/l of query 4g+r (held by the lanes with c == 4g+r)
+      const int qo = qblk * 16 + 4 * g + r;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float v = o[db][r] * il;
+        const float vn = __shfl_xor(v, 1, 64);
+        if ((c & 1) == 0 && qo < T)
+          *(unsigned int*)(out + ((long long)b * T + qo) * (H * HD) + h * HD + db * 16 + c) = pack_bf16x2(v, vn);
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// backward, part 1: dQ (query on the lane) and delta = rowsum(dO * O)
+// ----------------------------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int T,
+                                                          int H, float scale) {
+  constexpr int NPAIR = (NKB + 1) / 2;
+  constexpr int RP = NPAIR * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char Kr[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Kt[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Vr[RP * ROWB];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long ld = 3ll * H * HD, ldo = (long long)H * HD;
+  const bf16_t* base = qkv + (long long)b * T * ld;
+  const bf16_t* qb_ = base + h * HD;
+  const bf16_t* kb_ = base + (long long)H * HD + h * HD;
+  const bf16_t* vb_ = base + 2ll * H * HD + h * HD;
+  const bf16_t* ob_ = out + (long long)b * T * ldo + h * HD;
+  const bf16_t* dob_ = dout + (long long)b * T * ldo + h * HD;
+  stage_matrix<true, true>(kb_, ld, T, RP, Kr, Kt);
+  stage_matrix<true, false>(vb_, ld, T, RP, Vr, nullptr);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  for (int qblk = wave; qblk < NKB; qblk += 4) {
+    const int qrow = qblk * 16 + c;
+    bf16x8 qf[2], dof[2], of[2];
+    load_rowfrag(qb_, ld, qrow, T, g, qf);
+    load_rowfrag(dob_, ldo, qrow, T, g, dof);
+    load_rowfrag(ob_, ldo, qrow, T, g, of);
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += bf16_to_f32((bf16_t)dof[ks][j]) * bf16_to_f32((bf16_t)of[ks][j]);
+    dl = group_sum(dl);
+    const float lq = qrow < T ? lse[((long long)b * H + h) * T + qrow] : 0.f;
+    if (g == 0 && qrow < T) delta[((long long)b * H + h) * T + qrow] = dl;
+    f32x4 ds[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(Kr + row_img(kb * 16 + c, ks * 4 + g));
+        const bf16x8 vf = *(const bf16x8*)(Vr + row_img(kb * 16 + c, ks * 4 + g));
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T[key][query]
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T[key][query]
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb * 16 + 4 * g + r;
+        const float p = (key < T && qrow < T) ? __expf(s[r] * scale - lq) : 0.f;
+        ds[kb][r] = p * (dp[r] - dl) * scale;
+      }
+    }
+    // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
+    f32x4 dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < NPAIR; ++pp) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const bf16x8 dsf = pack_acc2(ds[2 * pp], (2 * pp + 1 < NKB) ? ds[2 * pp + 1] : zero);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 ktf = tr_pair(Kt, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, db, lane);   // A[d = db*16 + c][keys]
+        dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[db], 0, 0, 0);       // D[d 4g+r][query c]
+      }
+    }
+    if (qrow < T) {
+      bf16_t* dst = dqkv + ((long long)b * T + qrow) * ld + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        u32x2 pk;
+        pk[0] = pack_bf16x2(dq[db][0], dq[db][1]);
+        pk[1] = pack_bf16x2(dq[db][2], dq[db][3]);
+        *(u32x2*)(dst + db * 16 + 4 * g) = pk;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// backward, part 2: dK and dV (key on the lane; a wave owns whole key blocks and walks all queries)
+// ----------------------------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+  constexpr int NPAIR = (NKB + 1) / 2;
+  constexpr int RP = NPAIR * 32;
+  __shared__ __attribute__((aligned(16))) unsigned char Qr[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Qt[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Dr[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Dt[RP * ROWB];
+  __shared__ float s_lse[RP], s_dl[RP];
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const long long ld = 3ll * H * HD, ldo = (long long)H * HD;
+  const bf16_t* base = qkv + (long long)b * T * ld;
+  const bf16_t* qb_ = base + h * HD;
+  const bf16_t* kb_ = base + (long long)H * HD + h * HD;
+  const bf16_t* vb_ = base + 2ll * H * HD + h * HD;
+  const bf16_t* dob_ = dout + (long long)b * T * ldo + h * HD;
+  stage_matrix<true, true>(qb_, ld, T, RP, Qr, Qt);
+  stage_matrix<true, true>(dob_, ldo, T, RP, Dr, Dt);
+  for (int i = threadIdx.x; i < RP; i += 256) {
+    s_lse[i] = i < T ? lse[((long long)b * H + h) * T + i] : 0.f;
+    s_dl[i] = i < T ? delta[((long long)b * H + h) * T + i] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  for (int kblk = wave; kblk < NKB; kblk += 4) {
+    const int krow = kblk * 16 + c;
+    bf16x8 kf[2], vf[2];
+    load_rowfrag(kb_, ld, krow, T, g, kf);
+    load_rowfrag(vb_, ld, krow, T, g, vf);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+#pragma unroll
+    for (int pp = 0; pp < NPAIR; ++pp) {
+      f32x4 p2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qblk = 2 * pp + u;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 qf = *(const bf16x8*)(Qr + row_img(qblk * 16 + c, ks * 4 + g));
+          const bf16x8 df = *(const bf16x8*)(Dr + row_img(qblk * 16 + c, ks * 4 + g));
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], s, 0, 0, 0);     // S[query 4g+r][key c]
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dp, 0, 0, 0);   // dP[query][key]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qblk * 16 + 4 * g + r;   // < RP always (zero padded rows)
+          const float p = (q < T && krow < T) ? __expf(s[r] * scale - s_lse[q]) : 0.f;
+          p2[u][r] = p;
+          ds2[u][r] = p * (dp[r] - s_dl[q]) * scale;
+        }
+      }
+      const bf16x8 pf = pack_acc2(p2[0], p2[1]);     // B[k = queries 32pp + 4g + r | 32pp + 16 + 4g + r][col = key c]
+      const bf16x8 dsf = pack_acc2(ds2[0], ds2[1]);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 dotf = tr_pair(Dt, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, db, lane);   // A[d][queries] = dO^T
+        const bf16x8 qtf = tr_pair(Qt, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, db, lane);    // A[d][queries] = Q^T
+        dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[db], 0, 0, 0);        // dV^T[d 4g+r][key c]
+        dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[db], 0, 0, 0);        // dK^T[d 4g+r][key c]
+      }
+    }
+    if (krow < T) {
+      bf16_t* dstk = dqkv + ((long long)b * T + krow) * ld + (long long)H * HD + h * HD;
+      bf16_t* dstv = dqkv + ((long long)b * T + krow) * ld + 2ll * H * HD + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        u32x2 pk;
+        pk[0] = pack_bf16x2(dk[db][0], dk[db][1]); pk[1] = pack_bf16x2(dk[db][2], dk[db][3]);
+        *(u32x2*)(dstk + db * 16 + 4 * g) = pk;
+        pk[0] = pack_bf16x2(dv[db][0], dv[db][1]); pk[1] = pack_bf16x2(dv[db][2], dv[db][3]);
+        *(u32x2*)(dstv + db * 16 + 4 * g) = pk;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int icamd_attention_fwd_launch(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T, int H, float scale, hipStream_t s) {
+  const dim3 grid((unsigned)(B * H));
+  if (T <= 64) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), 0, s, qkv, out, lse, T, H, scale);
+  else if (T <= 208) hipLaunchKernelGGL(attn_fwd_kernel<13>, grid, dim3(256), 0, s, qkv, out, lse, T, H, scale);
+  else return ICAMD_ERR_UNSUPPORTED;
+  return icamd_launch_status();
+}
+
+int icamd_attention_bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
+                               bf16_t* dqkv, int B, int T, int H, float scale, hipStream_t s) {
+  const dim3 grid((unsigned)(B * H));
+  if (T <= 64) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(256), 0, s, qkv, out, dout, lse, delta, dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, T, H, scale);
+  } else if (T <= 208) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<13>, grid, dim3(256), 0, s, qkv, out, dout, lse, delta, dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<13>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, T, H, scale);
+  } else {
+    return ICAMD_ERR_UNSUPPORTED;
+  }
+  return icamd_launch_status();
+}

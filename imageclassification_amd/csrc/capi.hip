@@ -45,6 +45,20 @@ int icamd_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, hipStre
 int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
                                   int njobs, hipStream_t s);
 int icamd_colsum_launch(const bf16_t* x, int rows, int ld, int cols, float* out, int accumulate, hipStream_t s);
+int icamd_sum_partials_launch(const float* part, int nrows, int C, float* out1, float* out2, int accumulate, double* chunks,
+                              float* c1c2, hipStream_t s);
+int icamd_layernorm_fwd_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
+                               long long rows, int C, float eps, hipStream_t s);
+int icamd_layernorm_bwd_blocks(long long rows);
+int icamd_layernorm_bwd_launch(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd, const float* gamma,
+                               bf16_t* dx, float* part, long long rows, int C, hipStream_t s);
+int icamd_gelu_fwd_launch(const bf16_t* z, bf16_t* a, long long numel, hipStream_t s);
+int icamd_gelu_bwd_launch(const bf16_t* da, const bf16_t* z, bf16_t* dz, long long numel, hipStream_t s);
+int icamd_colsum_blocks(long long rows);
+int icamd_colsum_partial_launch(const bf16_t* x, float* part, long long rows, int ld, int cols, hipStream_t s);
+int icamd_attention_fwd_launch(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T, int H, float scale, hipStream_t s);
+int icamd_attention_bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
+                               bf16_t* dqkv, int B, int T, int H, float scale, hipStream_t s);
 int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
                                         int njobs, hipStream_t s);
 
@@ -345,6 +359,99 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
   ws += bn_chunk_bytes(C);
   return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
                                    (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream);
+}
+
+// ---- LayerNorm / GELU / column sums (ViT, ConvNeXt) -------------------------------------------------------------
+int icamd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        long long rows, int C, float eps, void* stream) {
+  ProfScope _prof(PC_BN_APPLY, stream);
+  if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || mean == nullptr || rstd == nullptr || rows <= 0 ||
+      C <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_layernorm_fwd_launch((const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, C, eps, (hipStream_t)stream);
+}
+
+// workspace: [counters|chunks] | partial rows [blocks][2][C] | scratch [2][C]
+size_t icamd_layernorm_bwd_workspace_bytes(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return bn_chunk_bytes(C) + align_up((size_t)icamd_layernorm_bwd_blocks(rows) * 2 * C * sizeof(float), 256) +
+         align_up((size_t)2 * C * sizeof(float), 256);
+}
+
+int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                        float* dgamma, float* dbeta, long long rows, int C, int accumulate, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (dy == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || gamma == nullptr || dx == nullptr ||
+      dgamma == nullptr || dbeta == nullptr || workspace == nullptr || rows <= 0 || C <= 0 || C > 4096)
+    return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < icamd_layernorm_bwd_workspace_bytes(rows, C)) return ICAMD_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(C);
+  float* part = (float*)ws;
+  const int nblk = icamd_layernorm_bwd_blocks(rows);
+  ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
+  int rc = icamd_layernorm_bwd_launch((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, part, rows, C,
+                                      (hipStream_t)stream);
+  if (rc) return rc;
+  return icamd_sum_partials_launch(part, nblk, C, dbeta, dgamma, accumulate, chunks, (float*)ws, (hipStream_t)stream);
+}
+
+int icamd_gelu_fwd(const void* z, void* a, long long numel, void* stream) {
+  ProfScope _prof(PC_BN_APPLY, stream);
+  if (z == nullptr || a == nullptr || numel <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_gelu_fwd_launch((const bf16_t*)z, (bf16_t*)a, numel, (hipStream_t)stream);
+}
+
+int icamd_gelu_bwd(const void* da, const void* z, void* dz, long long numel, void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (da == nullptr || z == nullptr || dz == nullptr || numel <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_gelu_bwd_launch((const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, numel, (hipStream_t)stream);
+}
+
+size_t icamd_colsum_rows_workspace_bytes(long long rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return bn_chunk_bytes(cols) + align_up((size_t)icamd_colsum_blocks(rows) * 2 * cols * sizeof(float), 256) +
+         align_up((size_t)3 * cols * sizeof(float), 256);
+}
+
+// out[c] = (accumulate ? out[c] : 0) + sum_r x[r][c], two-level, fixed order (bias gradients of long token matrices)
+int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* out, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_MISC, stream);
+  if (x == nullptr || out == nullptr || workspace == nullptr || rows <= 0 || cols <= 0 || cols > 4096 || ld < cols)
+    return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < icamd_colsum_rows_workspace_bytes(rows, cols)) return ICAMD_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(cols);
+  float* part = (float*)ws;
+  const int nblk = icamd_colsum_blocks(rows);
+  ws += align_up((size_t)nblk * 2 * cols * sizeof(float), 256);
+  float* scratch = (float*)ws;   // [3][cols]: discarded second sum + c1/c2
+  int rc = icamd_colsum_partial_launch((const bf16_t*)x, part, rows, ld, cols, (hipStream_t)stream);
+  if (rc) return rc;
+  return icamd_sum_partials_launch(part, nblk, cols, out, scratch, accumulate, chunks, scratch + cols, (hipStream_t)stream);
+}
+
+// ---- attention (ViT) --------------------------------------------------------------------------------------------
+int icamd_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, float scale, void* stream) {
+  ProfScope _prof(PC_IGEMM_FWD, stream);
+  if (qkv == nullptr || out == nullptr || lse == nullptr || B <= 0 || T <= 0 || H <= 0) return ICAMD_ERR_BAD_ARG;
+  if (D != 64) return ICAMD_ERR_UNSUPPORTED;
+  return icamd_attention_fwd_launch((const bf16_t*)qkv, (bf16_t*)out, lse, B, T, H, scale, (hipStream_t)stream);
+}
+
+int icamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                        int B, int T, int H, int D, float scale, void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  if (qkv == nullptr || out == nullptr || dout == nullptr || lse == nullptr || delta == nullptr || dqkv == nullptr || B <= 0 ||
+      T <= 0 || H <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  if (D != 64) return ICAMD_ERR_UNSUPPORTED;
+  return icamd_attention_bwd_launch((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, B,
+                                    T, H, scale, (hipStream_t)stream);
 }
 
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {

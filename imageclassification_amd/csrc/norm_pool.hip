@@ -603,6 +603,18 @@ int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, 
   return icamd_launch_status();
 }
 
+// Generic fold of per-workgroup partial rows part[nrows][2][C]: sum1 -> out1, sum2 -> out2 (fixed order, fp64 across rows)
+int icamd_sum_partials_launch(const float* part, int nrows, int C, float* out1, float* out2, int accumulate, double* chunks,
+                              float* c1c2, hipStream_t s) {
+  int rpc, nc;
+  chunking(nrows, &rpc, &nc);
+  BnFinalizeArgs a = {};
+  a.dgamma = out2; a.dbeta = out1; a.c1_out = c1c2; a.c2_out = c1c2 + C; a.accumulate = accumulate; a.count = 1.0;
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)((C + 63) / 64), (unsigned)nc), dim3(1024), 0, s, part, chunks,
+                     counters_of(chunks, C), nrows, C, rpc, a);
+  return icamd_launch_status();
+}
+
 int icamd_bn_eval_coeffs_launch(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                 float* scale, float* shift, hipStream_t s) {
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, C, gamma, beta, rm, rv,

@@ -117,6 +117,30 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
                                long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* ---- LayerNorm / GELU / long column sums (ViT and ConvNeXt layers of the same reference calls; LayerNorm spec
+ *      /root/reference/semantic_segmentation/backbone/convnext.py:158-182, exact-erf GELU :37) ------------------- */
+/* y = (x - mean_C) * rstd * gamma + beta over the last dimension of x [rows][C] (C % 4 == 0, C <= 1024);
+ * mean / rstd (float [rows]) are saved for the backward pass */
+int icamd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        long long rows, int C, float eps, void* stream);
+size_t icamd_layernorm_bwd_workspace_bytes(long long rows, int C);   /* zero-fill once (arrival counters) */
+int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                        float* dgamma, float* dbeta, long long rows, int C, int accumulate, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int icamd_gelu_fwd(const void* z, void* a, long long numel, void* stream);              /* a = z * Phi(z) (erf form) */
+int icamd_gelu_bwd(const void* da, const void* z, void* dz, long long numel, void* stream);
+size_t icamd_colsum_rows_workspace_bytes(long long rows, int cols);   /* zero-fill once */
+int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* out, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- multi-head self-attention for short sequences (timm Attention under the same reference calls, ViT-B/16:
+ *      T = 197 tokens, 12 heads of 64).  qkv: bf16 [B*T][3*H*D] (q | k | v, each [head][D]); out: bf16 [B*T][H*D];
+ *      lse / delta: float [B][H][T] (log-sum-exp of the scaled scores; rowsum(dout*out), scratch for the backward).
+ *      D must be 64, T <= 208.  One workgroup per (image, head); no atomics, fixed summation order. --------------- */
+int icamd_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, float scale, void* stream);
+int icamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                        int B, int T, int H, int D, float scale, void* stream);
+
 /* ---- pooling ---------------------------------------------------------------------------------------- */
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
 int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream);

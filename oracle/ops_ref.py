@@ -229,3 +229,52 @@ def bf16_close(a, b, ulps=2.0, atol_rms=2e-3):
     ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
     rms = float(torch.sqrt((b.double() ** 2).mean()))
     return bool(((a - b).abs() <= ulps * ulp + atol_rms * rms).all())
+
+
+# ---- token ops: LayerNorm / GELU / attention (ViT, ConvNeXt) ---------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps):
+    """x [rows, C] bf16-representable. Returns y (bf16 grid), mean, rstd."""
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = ((xf - mean[:, None]) ** 2).mean(-1)
+    rstd = torch.rsqrt(var + eps)
+    y = (xf - mean[:, None]) * rstd[:, None] * gamma.float() + beta.float()
+    return bf16_round(y), mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, eps):
+    """Gradients through torch's own layer_norm (fp32): dx (bf16 grid), dgamma, dbeta."""
+    xf = x.float().requires_grad_(True)
+    g = gamma.float().clone().requires_grad_(True)
+    b = torch.zeros_like(g).requires_grad_(True)
+    y = F.layer_norm(xf, (x.shape[-1],), g, b, eps)
+    y.backward(dy.float())
+    return bf16_round(xf.grad), g.grad, b.grad
+
+
+def gelu_fwd(z):
+    return bf16_round(F.gelu(z.float()))
+
+
+def gelu_bwd(da, z):
+    zf = z.float().requires_grad_(True)
+    F.gelu(zf).backward(da.float())
+    return bf16_round(zf.grad)
+
+
+def attention_fwd(qkv, B, T, H, D, scale):
+    """qkv [B*T, 3*H*D] (timm layout: reshape(B, T, 3, H, D)). Returns out [B*T, H*D] (bf16 grid), lse [B,H,T]."""
+    q, k, v = qkv.float().reshape(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.softmax(s, dim=-1)
+    o = p @ v
+    return bf16_round(o.permute(0, 2, 1, 3).reshape(B * T, H * D)), lse
+
+
+def attention_bwd(qkv, dout, B, T, H, D, scale):
+    x = qkv.float().requires_grad_(True)
+    q, k, v = x.reshape(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    o = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1) @ v
+    o.permute(0, 2, 1, 3).reshape(B * T, H * D).backward(dout.float())
+    return bf16_round(x.grad)

@@ -543,3 +543,93 @@ def test_conv_dgrad_addend_maskbits(lib):
     assert R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
     assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), None, hip.ptr(bd),
                                   hip.stream_ptr()) == 1      # bits without an addend: bad argument
+
+
+@pytest.mark.parametrize("rows,C", [(50, 768), (197 * 3, 768), (64, 96), (33, 384), (5, 1024)])
+def test_layernorm_fwd_bwd(lib, rows, C):
+    hip = _hip()
+    g = torch.Generator().manual_seed(100)
+    x = rnd_bf16(rows, C, scale=2.0, seed=101) + 0.5
+    x = R.bf16_round(x)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    ry, rmean, rrstd = R.layernorm_fwd(x, gamma, beta, 1e-6)
+    xd, gd, bd = to_dev_bf16(x), gamma.to(DEV), beta.to(DEV)
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    assert lib.icamd_layernorm_fwd(hip.ptr(xd), hip.ptr(gd), hip.ptr(bd), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), rows, C,
+                                   1e-6, hip.stream_ptr()) == 0
+    sync()
+    assert torch.allclose(mean.cpu(), rmean, rtol=1e-5, atol=1e-6) and torch.allclose(rstd.cpu(), rrstd, rtol=1e-5)
+    assert R.rel_l2(y.float().cpu(), ry) <= 1e-3 and R.bf16_close(y.float().cpu(), ry)
+    # the oracle's forward equals torch's layer_norm
+    assert torch.allclose(ry, R.bf16_round(torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-6)), atol=1e-2)
+    dy = rnd_bf16(rows, C, seed=102)
+    rdx, rdg, rdb = R.layernorm_bwd(dy, x, gamma, 1e-6)
+    wsb = lib.icamd_layernorm_bwd_workspace_bytes(rows, C)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    dx = torch.empty_like(y)
+    dg, db = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    dyd = to_dev_bf16(dy)
+    for acc in (0, 1):
+        assert lib.icamd_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gd), hip.ptr(dx),
+                                       hip.ptr(dg), hip.ptr(db), rows, C, acc, hip.ptr(ws), wsb, hip.stream_ptr()) == 0
+        sync()
+        assert R.rel_l2(dx.float().cpu(), rdx) <= 1e-3 and R.bf16_close(dx.float().cpu(), rdx)
+        assert R.rel_l2(dg.cpu(), (1 + acc) * rdg) <= 1e-4 and R.rel_l2(db.cpu(), (1 + acc) * rdb) <= 1e-4
+
+
+def test_gelu_and_colsum_rows(lib):
+    hip = _hip()
+    z = rnd_bf16(197 * 4, 3072, scale=2.0, seed=110)
+    zd = to_dev_bf16(z)
+    a = torch.empty_like(zd)
+    assert lib.icamd_gelu_fwd(hip.ptr(zd), hip.ptr(a), z.numel(), hip.stream_ptr()) == 0
+    sync()
+    ra = R.gelu_fwd(z)
+    assert R.rel_l2(a.float().cpu(), ra) <= 1e-3 and R.bf16_close(a.float().cpu(), ra)
+    da = rnd_bf16(197 * 4, 3072, seed=111)
+    dad = to_dev_bf16(da)
+    dz = torch.empty_like(zd)
+    assert lib.icamd_gelu_bwd(hip.ptr(dad), hip.ptr(zd), hip.ptr(dz), z.numel(), hip.stream_ptr()) == 0
+    sync()
+    rdz = R.gelu_bwd(da, z)
+    assert R.rel_l2(dz.float().cpu(), rdz) <= 1e-3 and R.bf16_close(dz.float().cpu(), rdz)
+    rows, ld, cols = 197 * 4, 3072, 3072
+    wsb = lib.icamd_colsum_rows_workspace_bytes(rows, cols)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    out = torch.full((cols,), 2.0, device=DEV)
+    assert lib.icamd_colsum_rows(hip.ptr(dz), rows, ld, cols, hip.ptr(out), 1, hip.ptr(ws), wsb, hip.stream_ptr()) == 0
+    sync()
+    ref = 2.0 + dz.float().cpu().double().sum(0).float()
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 197, 12), (3, 50, 4), (1, 64, 2), (2, 17, 3)])
+def test_attention_fwd_bwd(lib, B, T, H):
+    hip = _hip()
+    D = 64
+    scale = D ** -0.5
+    qkv = rnd_bf16(B * T, 3 * H * D, scale=1.0, seed=120)
+    ro, rlse = R.attention_fwd(qkv, B, T, H, D, scale)
+    qd = to_dev_bf16(qkv)
+    out = torch.full((B * T, H * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, T, device=DEV)
+    assert lib.icamd_attention_fwd(hip.ptr(qd), hip.ptr(out), hip.ptr(lse), B, T, H, D, scale, hip.stream_ptr()) == 0
+    sync()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert torch.allclose(lse.cpu(), rlse, rtol=1e-4, atol=1e-4)
+    assert R.rel_l2(got, ro) <= 3e-3 and R.bf16_close(got, ro, ulps=2.0, atol_rms=8e-3)   # P is rounded to bf16 before P@V
+    dout = rnd_bf16(B * T, H * D, seed=121)
+    rd = R.attention_bwd(qkv, dout, B, T, H, D, scale)
+    dd = to_dev_bf16(dout)
+    delta = torch.empty(B, H, T, device=DEV)
+    dqkv = torch.full((B * T, 3 * H * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib.icamd_attention_bwd(hip.ptr(qd), hip.ptr(out), hip.ptr(dd), hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv), B, T, H,
+                                   D, scale, hip.stream_ptr()) == 0
+    sync()
+    gd = dqkv.float().cpu()
+    assert torch.isfinite(gd).all()
+    for name, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, 2 * H * D)), ("dv", slice(2 * H * D, 3 * H * D))):
+        assert R.rel_l2(gd[:, sl], rd[:, sl]) <= 6e-3, name      # P, dS pass through bf16 MFMA operands
