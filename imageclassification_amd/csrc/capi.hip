@@ -51,7 +51,12 @@ int icamd_layernorm_fwd_launch(const bf16_t* x, const float* gamma, const float*
                                long long rows, int C, float eps, hipStream_t s);
 int icamd_layernorm_bwd_blocks(long long rows);
 int icamd_layernorm_bwd_launch(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd, const float* gamma,
-                               bf16_t* dx, float* part, long long rows, int C, hipStream_t s);
+                               const bf16_t* addend, bf16_t* dx, float* part, long long rows, int C, hipStream_t s);
+int icamd_vit_tokens_fwd_launch(const bf16_t* patches, const float* cls, const float* pos, bf16_t* tok, int B, int T, int C,
+                                hipStream_t s);
+int icamd_batch_sum_launch(const bf16_t* x, long long stride, int B, long long n, float* out, int accumulate, hipStream_t s);
+int icamd_strided_rows_copy_launch(const bf16_t* src, long long sstride, bf16_t* dst, long long dstride, long long rows,
+                                   long long C, hipStream_t s);
 int icamd_gelu_fwd_launch(const bf16_t* z, bf16_t* a, long long numel, hipStream_t s);
 int icamd_gelu_bwd_launch(const bf16_t* da, const bf16_t* z, bf16_t* dz, long long numel, hipStream_t s);
 int icamd_colsum_blocks(long long rows);
@@ -93,7 +98,8 @@ bool conv_desc_ok(const icamd_conv_desc* d) {
   if (d == nullptr) return false;
   if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->Cin <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0) return false;
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return false;
-  if (d->KH * d->KW > ICAMD_MAX_TAPS) return false;
+  if (d->Cin != 8 && d->KH * d->KW > ICAMD_MAX_TAPS) return false;   // the 8-channel stem path derives taps arithmetically
+  if (d->KH * d->KW > 1024) return false;
   if ((d->IH + 2 * d->pad - d->KH) / d->stride + 1 != d->OH) return false;
   if ((d->IW + 2 * d->pad - d->KW) / d->stride + 1 != d->OW) return false;
   return true;
@@ -146,11 +152,12 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
   p.ostr = 1; p.ooff_h = 0; p.ooff_w = 0; p.istr = d->stride;
   p.ntaps = d->KH * d->KW; p.Ktot = p.ntaps * d->Cin;
   p.KW = d->KW; p.pad = d->pad;
-  for (int r = 0; r < d->KH; ++r)
-    for (int s = 0; s < d->KW; ++s) {
-      const int t = r * d->KW + s;
-      p.dh[t] = (short)(r - d->pad); p.dw[t] = (short)(s - d->pad); p.wtap[t] = (short)t;
-    }
+  if (p.ntaps <= ICAMD_MAX_TAPS)
+    for (int r = 0; r < d->KH; ++r)
+      for (int s = 0; s < d->KW; ++s) {
+        const int t = r * d->KW + s;
+        p.dh[t] = (short)(r - d->pad); p.dw[t] = (short)(s - d->pad); p.wtap[t] = (short)t;
+      }
   return icamd_igemm_launch(p, (hipStream_t)stream);
 }
 
@@ -378,9 +385,9 @@ size_t icamd_layernorm_bwd_workspace_bytes(long long rows, int C) {
          align_up((size_t)2 * C * sizeof(float), 256);
 }
 
-int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
-                        float* dgamma, float* dbeta, long long rows, int C, int accumulate, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        const void* addend, void* dx, float* dgamma, float* dbeta, long long rows, int C, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
   if (dy == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || gamma == nullptr || dx == nullptr ||
       dgamma == nullptr || dbeta == nullptr || workspace == nullptr || rows <= 0 || C <= 0 || C > 4096)
@@ -392,8 +399,8 @@ int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const 
   float* part = (float*)ws;
   const int nblk = icamd_layernorm_bwd_blocks(rows);
   ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
-  int rc = icamd_layernorm_bwd_launch((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, part, rows, C,
-                                      (hipStream_t)stream);
+  int rc = icamd_layernorm_bwd_launch((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)addend,
+                                      (bf16_t*)dx, part, rows, C, (hipStream_t)stream);
   if (rc) return rc;
   return icamd_sum_partials_launch(part, nblk, C, dbeta, dgamma, accumulate, chunks, (float*)ws, (hipStream_t)stream);
 }
@@ -433,6 +440,32 @@ int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* ou
   int rc = icamd_colsum_partial_launch((const bf16_t*)x, part, rows, ld, cols, (hipStream_t)stream);
   if (rc) return rc;
   return icamd_sum_partials_launch(part, nblk, cols, out, scratch, accumulate, chunks, scratch + cols, (hipStream_t)stream);
+}
+
+int icamd_vit_tokens_fwd(const void* patches, const float* cls_token, const float* pos_embed, void* tokens, int B, int T, int C,
+                         void* stream) {
+  ProfScope _prof(PC_MISC, stream);
+  if (patches == nullptr || cls_token == nullptr || pos_embed == nullptr || tokens == nullptr || B <= 0 || T <= 1 || C <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_vit_tokens_fwd_launch((const bf16_t*)patches, cls_token, pos_embed, (bf16_t*)tokens, B, T, C, (hipStream_t)stream);
+}
+
+int icamd_batch_sum(const void* x, long long stride, int B, long long n, float* out, int accumulate, void* stream) {
+  ProfScope _prof(PC_MISC, stream);
+  if (x == nullptr || out == nullptr || B <= 0 || n <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_batch_sum_launch((const bf16_t*)x, stride, B, n, out, accumulate, (hipStream_t)stream);
+}
+
+int icamd_strided_rows_copy(const void* src, long long src_stride, void* dst, long long dst_stride, long long rows, long long C,
+                            void* stream) {
+  ProfScope _prof(PC_MISC, stream);
+  if (src == nullptr || dst == nullptr || rows <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_strided_rows_copy_launch((const bf16_t*)src, src_stride, (bf16_t*)dst, dst_stride, rows, C, (hipStream_t)stream);
+}
+
+int icamd_fill_zero(void* ptr, size_t bytes, void* stream) {
+  if (ptr == nullptr) return ICAMD_ERR_BAD_ARG;
+  return hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream) == hipSuccess ? ICAMD_OK : ICAMD_ERR_LAUNCH;
 }
 
 // ---- attention (ViT) --------------------------------------------------------------------------------------------

@@ -397,7 +397,7 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   if ((long long)p.N * p.IH * p.IW * p.Cin >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.Cout * p.Ktot >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.N * p.OH * p.OW * p.Cout >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
-  if (p.M <= 0 || p.ntaps < 0 || p.ntaps > ICAMD_MAX_TAPS) return ICAMD_ERR_BAD_ARG;
+  if (p.M <= 0 || p.ntaps < 0 || (!cin8 && p.ntaps > ICAMD_MAX_TAPS)) return ICAMD_ERR_BAD_ARG;
   const int bn = icamd_igemm_pick_bn(p.Cout);
   p.ntiles_n = (p.Cout + bn - 1) / bn;
   p.ksteps = (p.ntaps * p.Cin + BK - 1) / BK;

@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // dy (-> dbeta) and dy*xhat (-> dgamma) in part[blk][2][C].  Each wave walks `rows_per_wave` rows.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, bf16_t* __restrict__ dx,
-                                                            float* __restrict__ part, long long rows, int C,
-                                                            int rows_per_wave) {
+                                                            const float* __restrict__ gamma, const bf16_t* __restrict__ addend,
+                                                            bf16_t* __restrict__ dx, float* __restrict__ part, long long rows,
+                                                            int C, int rows_per_wave) {
   __shared__ float red[4][2][LN_MAX_IT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nit = (C + 255) / 256;
@@ -124,6 +124,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (dyg[it][e] - c1 - xh[it][e] * c2);
+          if (addend != nullptr) {   // residual branch: the skip connection's gradient joins here
+            float a4[4];
+            unpack4(*(const u32x2*)(addend + row * C + c), a4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += a4[e];
+          }
           u32x2 pk;
           pk[0] = pack_bf16x2(o[0], o[1]);
           pk[1] = pack_bf16x2(o[2], o[3]);
@@ -220,6 +226,64 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   }
 }
 
+// ViT token assembly: tok[b][0] = cls + pos[0]; tok[b][1+i] = patch[b][i] + pos[1+i]   (C % 8 == 0)
+__global__ __launch_bounds__(256) void vit_tokens_fwd_kernel(const bf16_t* __restrict__ patches, const float* __restrict__ cls,
+                                                             const float* __restrict__ pos, bf16_t* __restrict__ tok, int B,
+                                                             int T, int C) {
+  const int cpr = C >> 3;
+  const long long total = (long long)B * T * cpr;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cg = (int)(i % cpr);
+    const long long row = i / cpr;
+    const int t = (int)(row % T);
+    const int b = (int)(row / T);
+    float v[8];
+    if (t == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = cls[cg * 8 + e];
+    } else {
+      const u32x4 p = ((const u32x4*)patches)[((long long)b * (T - 1) + (t - 1)) * cpr + cg];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] = bf16_lo(p[e]); v[2 * e + 1] = bf16_hi(p[e]); }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack_bf16x2(v[2 * e] + pos[(long long)t * C + cg * 8 + 2 * e], v[2 * e + 1] + pos[(long long)t * C + cg * 8 + 2 * e + 1]);
+    ((u32x4*)tok)[i] = o;
+  }
+}
+
+// out[j] = (accumulate ? out[j] : 0) + sum_b x[b*stride + j], j < n (n % 8 == 0): gradients of cls_token / pos_embed
+__global__ __launch_bounds__(256) void batch_sum_kernel(const bf16_t* __restrict__ x, long long stride, int B, long long n8,
+                                                        float* __restrict__ out, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const u32x4 v = *(const u32x4*)(x + (long long)b * stride + i * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[2 * e] += bf16_lo(v[e]); s[2 * e + 1] += bf16_hi(v[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[i * 8 + e] = accumulate ? out[i * 8 + e] + s[e] : s[e];
+}
+
+// dst[r][0..C) = src[r][0..C) for r < rows, with independent row strides (elements; C % 8 == 0)
+__global__ __launch_bounds__(256) void strided_rows_copy_kernel(const bf16_t* __restrict__ src, long long sstride,
+                                                                bf16_t* __restrict__ dst, long long dstride, long long rows,
+                                                                long long c8) {
+  const long long total = rows * c8;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long r = i / c8, c = i - r * c8;
+    *(u32x4*)(dst + r * dstride + c * 8) = *(const u32x4*)(src + r * sstride + c * 8);
+  }
+}
+
 inline unsigned int ew_grid(long long nvec) {
   long long blocks = (nvec + 255) / 256;
   if (blocks > 1024) blocks = 1024;
@@ -244,12 +308,12 @@ int icamd_layernorm_bwd_blocks(long long rows) {
 }
 
 int icamd_layernorm_bwd_launch(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd, const float* gamma,
-                               bf16_t* dx, float* part, long long rows, int C, hipStream_t s) {
+                               const bf16_t* addend, bf16_t* dx, float* part, long long rows, int C, hipStream_t s) {
   if (C % 4 != 0 || C > LN_MAX_IT * 256) return ICAMD_ERR_UNSUPPORTED;
   const int nblk = icamd_layernorm_bwd_blocks(rows);
   const int rpw = (int)((rows + (long long)nblk * 4 - 1) / ((long long)nblk * 4));
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dy, x, mean, rstd, gamma, dx, part, rows, C,
-                     rpw);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dy, x, mean, rstd, gamma, addend, dx, part,
+                     rows, C, rpw);
   return icamd_launch_status();
 }
 
@@ -276,5 +340,28 @@ int icamd_colsum_partial_launch(const bf16_t* x, float* part, long long rows, in
   const int nblk = icamd_colsum_blocks(rows);
   const int rpb = (int)((rows + nblk - 1) / nblk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, x, part, rows, ld, cols, rpb);
+  return icamd_launch_status();
+}
+
+int icamd_vit_tokens_fwd_launch(const bf16_t* patches, const float* cls, const float* pos, bf16_t* tok, int B, int T, int C,
+                                hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(vit_tokens_fwd_kernel, dim3(ew_grid((long long)B * T * (C / 8))), dim3(256), 0, s, patches, cls, pos, tok, B,
+                     T, C);
+  return icamd_launch_status();
+}
+
+int icamd_batch_sum_launch(const bf16_t* x, long long stride, int B, long long n, float* out, int accumulate, hipStream_t s) {
+  if (n % 8 != 0 || stride % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long n8 = n / 8;
+  hipLaunchKernelGGL(batch_sum_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, x, stride, B, n8, out, accumulate);
+  return icamd_launch_status();
+}
+
+int icamd_strided_rows_copy_launch(const bf16_t* src, long long sstride, bf16_t* dst, long long dstride, long long rows,
+                                   long long C, hipStream_t s) {
+  if (C % 8 != 0 || sstride % 8 != 0 || dstride % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(strided_rows_copy_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0, s, src, sstride, dst, dstride, rows,
+                     C / 8);
   return icamd_launch_status();
 }

@@ -14,7 +14,8 @@ class ModelEmaV3:
     def __init__(self, model, decay=0.9999, device=None):
         self.decay = decay
         self.lib = hip.load()
-        self.module = type(model)(arch=model.arch, num_classes=model.num_classes, device=str(model.device))
+        kw = {"img_size": model.img_size} if hasattr(model, "img_size") else {}
+        self.module = type(model)(arch=model.arch, num_classes=model.num_classes, device=str(model.device), **kw)
         self.module.eval()
         self.set(model)
 

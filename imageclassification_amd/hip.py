@@ -60,11 +60,15 @@ _SIGNATURES = {
     "icamd_bn_bwd_from_partials": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
     "icamd_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_float, _P]),
     "icamd_layernorm_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
-    "icamd_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
+    "icamd_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
     "icamd_gelu_fwd": (c_int, [_P, _P, c_longlong, _P]),
     "icamd_gelu_bwd": (c_int, [_P, _P, _P, c_longlong, _P]),
     "icamd_colsum_rows_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "icamd_colsum_rows": (c_int, [_P, c_longlong, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+    "icamd_vit_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "icamd_batch_sum": (c_int, [_P, c_longlong, c_int, c_longlong, _P, c_int, _P]),
+    "icamd_strided_rows_copy": (c_int, [_P, c_longlong, _P, c_longlong, c_longlong, c_longlong, _P]),
+    "icamd_fill_zero": (c_int, [_P, c_size_t, _P]),
     "icamd_attention_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "icamd_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "icamd_maxpool3x3s2_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -124,14 +124,24 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
 int icamd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                         long long rows, int C, float eps, void* stream);
 size_t icamd_layernorm_bwd_workspace_bytes(long long rows, int C);   /* zero-fill once (arrival counters) */
-int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
-                        float* dgamma, float* dbeta, long long rows, int C, int accumulate, void* workspace,
-                        size_t workspace_bytes, void* stream);
+/* dx = LayerNorm-backward(dy) (+ addend: the skip connection's gradient, same shape) */
+int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        const void* addend, void* dx, float* dgamma, float* dbeta, long long rows, int C, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream);
 int icamd_gelu_fwd(const void* z, void* a, long long numel, void* stream);              /* a = z * Phi(z) (erf form) */
 int icamd_gelu_bwd(const void* da, const void* z, void* dz, long long numel, void* stream);
 size_t icamd_colsum_rows_workspace_bytes(long long rows, int cols);   /* zero-fill once */
 int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* out, int accumulate, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* ViT token plumbing: tokens[b][0] = cls + pos[0], tokens[b][1+i] = patches[b][i] + pos[1+i] (bf16 out, fp32 parameters);
+ * batch_sum: out[j] (+)= sum_b x[b*stride + j] (cls_token / pos_embed gradients); strided row copies; zero fill. */
+int icamd_vit_tokens_fwd(const void* patches, const float* cls_token, const float* pos_embed, void* tokens, int B, int T, int C,
+                         void* stream);
+int icamd_batch_sum(const void* x, long long stride, int B, long long n, float* out, int accumulate, void* stream);
+int icamd_strided_rows_copy(const void* src, long long src_stride, void* dst, long long dst_stride, long long rows, long long C,
+                            void* stream);
+int icamd_fill_zero(void* ptr, size_t bytes, void* stream);
 
 /* ---- multi-head self-attention for short sequences (timm Attention under the same reference calls, ViT-B/16:
  *      T = 197 tokens, 12 heads of 64).  qkv: bf16 [B*T][3*H*D] (q | k | v, each [head][D]); out: bf16 [B*T][H*D];

@@ -572,7 +572,7 @@ def test_layernorm_fwd_bwd(lib, rows, C):
     dg, db = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
     dyd = to_dev_bf16(dy)
     for acc in (0, 1):
-        assert lib.icamd_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gd), hip.ptr(dx),
+        assert lib.icamd_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gd), None, hip.ptr(dx),
                                        hip.ptr(dg), hip.ptr(db), rows, C, acc, hip.ptr(ws), wsb, hip.stream_ptr()) == 0
         sync()
         assert R.rel_l2(dx.float().cpu(), rdx) <= 1e-3 and R.bf16_close(dx.float().cpu(), rdx)

@@ -91,6 +91,17 @@ def test_resnet_oracle_parameter_counts_and_names():
     assert float(ResNetRef("resnet18").layer1[0].bn2.weight.abs().sum()) == 0.0
 
 
+def test_vit_oracle_parameter_count():
+    from oracle.vit_ref import ViTRef
+    m = ViTRef("vit_tiny_test", 10, img_size=64)
+    out = m(torch.randn(2, 3, 64, 64))
+    assert out.shape == (2, 10)
+    names = [n for n, _ in m.named_parameters()]
+    for k in ("cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.bias",
+              "norm.weight", "head.bias"):
+        assert k in names
+
+
 def test_oracle_ops_agree_with_torch_primitives():
     g = torch.Generator().manual_seed(0)
     y = R.bf16_round(torch.randn(4, 5, 5, 16, generator=g))
