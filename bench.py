@@ -51,6 +51,18 @@ def conv_flops_per_image(net, hw):
     return layers
 
 
+def vit_flops_per_image(net):
+    """Algorithmic forward FLOPs of every Linear (as [name, flops]) plus the attention products."""
+    T, D, Hd = net.T, net.dim, net.hidden
+    layers = [("patch_embed", 2 * (T - 1) * D * 3 * net.patch * net.patch)]
+    for i in range(net.depth):
+        layers += [(f"blocks.{i}.qkv", 2 * T * D * 3 * D), (f"blocks.{i}.proj", 2 * T * D * D),
+                   (f"blocks.{i}.fc1", 2 * T * D * Hd), (f"blocks.{i}.fc2", 2 * T * Hd * D),
+                   (f"blocks.{i}.attention", 4 * net.heads * T * T * 64)]
+    layers.append(("head", 2 * D * net.num_classes))
+    return layers
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -102,13 +114,16 @@ def main():
     from imageclassification_amd.ddp import DistributedDataParallel
     from imageclassification_amd.engine import train_one_epoch
     from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
-    from imageclassification_amd.nets import ResNet
+    from imageclassification_amd.nets import ARCHS, ResNet
+    from imageclassification_amd.vit import VisionTransformer
     from imageclassification_amd.optim_factory import create_optimizer
     from imageclassification_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
 
     lib = hip.load()
     C, B, HW = 1000, args.batch, args.hw
-    net = ResNet(args.arch, C, device=str(device), seed=88)
+    is_vit = args.arch not in ARCHS
+    net = VisionTransformer(args.arch, C, device=str(device), img_size=HW, seed=88) if is_vit else \
+        ResNet(args.arch, C, device=str(device), seed=88)
     model = DistributedDataParallel(net) if world > 1 else net
     opt = create_optimizer("adamw", 1e-3, 5e-4, net)
     crit = LabelSmoothingCrossEntropy(0.1)
@@ -166,8 +181,8 @@ def main():
     psteps = prof_steps
 
     if rank == 0:
-        layers = conv_flops_per_image(net, HW)
-        fwd_flops = sum(f for _, f in layers) * B           # per step, all conv/FC forward launches
+        layers = vit_flops_per_image(net) if is_vit else conv_flops_per_image(net, HW)
+        fwd_flops = sum(f for _, f in layers) * B           # per step, all conv/FC (and attention) forward launches
         stem_flops = layers[0][1] * B
         algo = {"conv_fwd": fwd_flops, "conv_dgrad": fwd_flops - stem_flops, "conv_wgrad": fwd_flops}
         kern = {}
@@ -180,6 +195,8 @@ def main():
         per_launch_flops = algo[dom] / kern[dom]["calls_per_step"]
         traffic = None
         try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/)
+            if args.arch != "resnet50" or B != 256:
+                raise KeyError("PMC traffic was collected for the ResNet-50 bs-256 workload only")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             names = {"conv_wgrad": "conv_wgrad_kernel", "conv_fwd": "conv_igemm_kernel", "conv_dgrad": "conv_igemm_kernel"}
             sel = [v for k, v in pmc["kernels"].items() if k.startswith(names[dom])]
@@ -205,12 +222,13 @@ def main():
             cpu = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
                    "sample": f"{args.cpu_steps} steps of batch 32 (1 warm-up), torch-CPU fp32 restatement of engine.py "
                              f"train_one_epoch, {args.arch} {HW}x{HW}, AdamW+label smoothing"}
-        out = {"metric": "images/sec (whole node) ResNet-50 bf16 224^2 training", "value": round(value, 2),
+        label = {"resnet50": "ResNet-50", "vit_base_patch16_224": "ViT-B/16"}.get(args.arch, args.arch)
+        out = {"metric": f"images/sec (whole node) {label} bf16 {HW}^2 training", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, "
-                                      f"label smoothing 0.1, 1000 classes (BASELINE configs[{1 if world == 1 else 2}])",
+                                      f"label smoothing 0.1, 1000 classes (BASELINE configs[{3 if is_vit else (1 if world == 1 else 2)}])",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
                "kernel_timing": {"method": "HIP events on the launch stream around every C-ABI call, separate pass",
