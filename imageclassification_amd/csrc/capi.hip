@@ -98,7 +98,7 @@ bool conv_desc_ok(const icamd_conv_desc* d) {
   if (d == nullptr) return false;
   if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->Cin <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0) return false;
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return false;
-  if (d->Cin != 8 && d->KH * d->KW > ICAMD_MAX_TAPS) return false;   // the 8-channel stem path derives taps arithmetically
+  if (d->Cin % 64 == 0 && d->KH * d->KW > ICAMD_MAX_TAPS) return false;   // the general path derives taps arithmetically
   if (d->KH * d->KW > 1024) return false;
   if ((d->IH + 2 * d->pad - d->KH) / d->stride + 1 != d->OH) return false;
   if ((d->IW + 2 * d->pad - d->KW) / d->stride + 1 != d->OW) return false;
@@ -151,7 +151,7 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
   p.P = d->OH; p.Q = d->OW; p.M = d->N * d->OH * d->OW;
   p.ostr = 1; p.ooff_h = 0; p.ooff_w = 0; p.istr = d->stride;
   p.ntaps = d->KH * d->KW; p.Ktot = p.ntaps * d->Cin;
-  p.KW = d->KW; p.pad = d->pad;
+  p.KW = d->KW; p.pad = d->pad; p.tap_sign = 1; p.regular_taps = 1;
   if (p.ntaps <= ICAMD_MAX_TAPS)
     for (int r = 0; r < d->KH; ++r)
       for (int s = 0; s < d->KW; ++s) {
@@ -164,7 +164,7 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
 static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
                       const uint8_t* addend_bits, const icamd_bn_bwd_fuse* f, void* stream) {
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
-  if (d->Cout % 64 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
+  if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
   float* partials = f ? f->partials : nullptr;
@@ -184,7 +184,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
       p.P = P; p.Q = Q; p.M = d->N * P * Q;
       p.ostr = st; p.ooff_h = ph; p.ooff_w = pw; p.istr = 1;
       p.Ktot = d->KH * d->KW * d->Cout;
-      p.KW = d->KW; p.pad = d->pad;
+      p.KW = d->KW; p.pad = d->pad; p.tap_sign = -1; p.regular_taps = (st == 1) ? 1 : 0;
       if (f != nullptr) {
         p.bnb_y = (const bf16_t*)f->y; p.bnb_mask = (const bf16_t*)f->mask_src;
         p.bnb_mean = f->mean; p.bnb_invstd = f->invstd; p.bnb_scale = f->scale; p.bnb_shift = f->shift;
@@ -199,7 +199,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
           const int ew = pw + d->pad - s;
           if (((ew % st) + st) % st != 0) continue;
           // exact division (eh, ew are multiples of st, possibly negative)
-          p.dh[nt] = (short)(eh / st); p.dw[nt] = (short)(ew / st); p.wtap[nt] = (short)(r * d->KW + s);
+          if (nt < ICAMD_MAX_TAPS) { p.dh[nt] = (short)(eh / st); p.dw[nt] = (short)(ew / st); p.wtap[nt] = (short)(r * d->KW + s); }
           ++nt;
         }
       }

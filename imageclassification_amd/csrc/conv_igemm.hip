@@ -119,24 +119,27 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
       }
     } else {
-      // Cin == 8 (padded stem): every 16 B chunk is its own tap; taps follow the regular (r,s) rule
+      // General channel counts (Cin % 8 == 0, e.g. the 8-channel padded RGB stem or ConvNeXt's 96): a 64-wide k-step
+      // may straddle taps, so every 16 B chunk derives its own (tap, channel) from k = tap*Cin + ci; taps follow the
+      // regular rule dh = sign*(r - pad) (sign = -1 for a stride-1 data gradient)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int t = ks * 8 + (a_lc[j] >> 3);
-        const int r = t / p.KW, s = t - r * p.KW;
-        const int dh = r - p.pad, dw = s - p.pad;
+        const unsigned int kk = (unsigned)(ks * BK + a_lc[j]);
+        const unsigned int t = fdiv(kk, p.divCin);
+        const int ci = (int)(kk - t * p.Cin);
+        const unsigned int r = fdiv(t, p.divKW);
+        const int dh = p.tap_sign * ((int)r - p.pad), dw = p.tap_sign * ((int)(t - r * p.KW) - p.pad);
         const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-        const bool ok = (t < p.ntaps) && ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
-        const bf16_t* src = ok ? in + (a_base[j] + (dh * p.IW + dw) * 8) : zero;
+        const bool ok = ((int)t < p.ntaps) && ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
+        const bf16_t* src = ok ? in + (a_base[j] + (dh * p.IW + dw) * p.Cin + ci) : zero;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * 32 + j * 8) * 128), 16, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < BROWS; ++j) {
         const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
-        const int lc = ((lane & 7) ^ ((row >> 1) & 7));
-        const int t = ks * 8 + lc;
-        // b_off already holds co*Ktot + lc*8; the step adds ks*64
-        const bf16_t* src = (b_off[j] >= 0 && t < p.ntaps) ? wt + (b_off[j] + ks * BK) : zero;
+        const int lc = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        // b_off already holds co*Ktot + lc; the filter row is k-contiguous in the same (tap, ci) order
+        const bf16_t* src = (b_off[j] >= 0 && ks * BK + lc < p.Ktot) ? wt + (b_off[j] + ks * BK) : zero;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
       }
     }
@@ -392,8 +395,10 @@ int icamd_igemm_pick_bn(int Cout) { return Cout <= 64 ? 64 : 128; }
 
 int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   if (p.Cout % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
-  const bool cin8 = (p.Cin == 8);
-  if (!cin8 && (p.Cin % 64 != 0)) return ICAMD_ERR_UNSUPPORTED;
+  const bool cin8 = (p.Cin % 64 != 0);   // "general" path: per-chunk taps (the 8-channel stem, ConvNeXt's 96, ...)
+  if (p.Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
+  if (cin8 && !p.regular_taps) return ICAMD_ERR_UNSUPPORTED;   // strided data gradients need Cout % 64 == 0
+  if (cin8 && p.Ktot != p.ntaps * p.Cin) return ICAMD_ERR_BAD_ARG;
   if ((long long)p.N * p.IH * p.IW * p.Cin >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.Cout * p.Ktot >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.N * p.OH * p.OW * p.Cout >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
@@ -403,6 +408,9 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   p.ksteps = (p.ntaps * p.Cin + BK - 1) / BK;
   p.divPQ = make_fastdiv((unsigned)(p.P * p.Q));
   p.divQ = make_fastdiv((unsigned)p.Q);
+  p.divCin = make_fastdiv((unsigned)p.Cin);
+  p.divKW = make_fastdiv((unsigned)(p.KW > 0 ? p.KW : 1));
+  if (p.tap_sign == 0) p.tap_sign = 1;
   if (p.bnb_y != nullptr) {
     if (cin8 || p.stats == nullptr || p.bnb_mean == nullptr || p.bnb_invstd == nullptr) return ICAMD_ERR_BAD_ARG;
     if (p.bnb_relu && p.bnb_mask == nullptr && (p.bnb_scale == nullptr || p.bnb_shift == nullptr)) return ICAMD_ERR_BAD_ARG;

@@ -24,9 +24,10 @@ struct IgemmParams {
   int P, Q, M;           // output sub-grid and row count N*P*Q
   int ostr, ooff_h, ooff_w, istr;
   int ntaps, Ktot;       // active taps; filter row length (elements)
-  int KW, pad;           // regular-tap rule for the Cin==8 stem path
+  int KW, pad;           // regular-tap rule of the general (Cin % 64 != 0) path: dh = tap_sign*(r - pad)
+  int tap_sign, regular_taps;
   int ksteps, ntiles_n;  // filled by the launcher
-  FastDiv divPQ, divQ;   // filled by the launcher
+  FastDiv divPQ, divQ, divCin, divKW;   // filled by the launcher
   short dh[ICAMD_MAX_TAPS], dw[ICAMD_MAX_TAPS], wtap[ICAMD_MAX_TAPS];
 };
 int icamd_igemm_launch(IgemmParams& p, hipStream_t stream);

@@ -51,6 +51,11 @@ CONV_CASES = [
     (4, 1, 1, 2048, 1024, 1, 1, 0),   # FC as a 1x1 convolution (1000 classes padded to 1024)
     (2, 16, 16, 8, 64, 7, 2, 3),      # stem: RGB zero-padded to 8 channels
     (1, 5, 5, 64, 72, 3, 1, 1),       # Cout not a multiple of the tile
+    (2, 12, 12, 96, 192, 2, 2, 0),    # ConvNeXt downsample: Cin = 96, k-steps straddle taps (general path)
+    (2, 8, 8, 96, 384, 1, 1, 0),      # ConvNeXt pwconv1 at dim 96
+    (2, 8, 8, 384, 96, 1, 1, 0),      # ConvNeXt pwconv2 at dim 96 (Cout = 96)
+    (2, 16, 16, 8, 96, 4, 4, 0),      # ConvNeXt stem: 4x4 stride 4 on the padded RGB input
+    (1, 32, 32, 8, 128, 16, 16, 0),   # ViT patch embedding: 16x16 stride 16 (256 taps)
 ]
 
 
@@ -96,6 +101,10 @@ DGRAD_CASES = [
     (2, 13, 11, 64, 128, 3, 2, 1),     # odd sizes: unequal parity classes
     (2, 14, 14, 256, 512, 1, 2, 0),
     (4, 1, 1, 2048, 1024, 1, 1, 0),
+    (2, 8, 8, 96, 384, 1, 1, 0),      # dx has 96 channels
+    (2, 8, 8, 384, 96, 1, 1, 0),      # GEMM-K = 96: general path with negated taps
+    (2, 9, 9, 64, 96, 3, 1, 1),       # 3x3 with Cout = 96: general path, taps straddle k-steps
+    (2, 12, 12, 96, 192, 2, 2, 0),    # ConvNeXt downsample gradient: 4 parity classes of one tap each
 ]
 
 
