@@ -64,6 +64,16 @@ int icamd_colsum_partial_launch(const bf16_t* x, float* part, long long rows, in
 int icamd_attention_fwd_launch(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T, int H, float scale, hipStream_t s);
 int icamd_attention_bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, float* delta,
                                bf16_t* dqkv, int B, int T, int H, float scale, hipStream_t s);
+int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* addend, bf16_t* y, int N, int H,
+                         int W, int C, int flip, hipStream_t s);
+int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C);
+int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, int N, int H, int W, int C,
+                               int accumulate, hipStream_t s);
+int icamd_layerscale_fwd_launch(const bf16_t* z, const bf16_t* inp, const float* gamma, const float* keep, bf16_t* out,
+                                long long rows, int C, long long rows_per_image, hipStream_t s);
+int icamd_layerscale_bwd_blocks(long long rows);
+int icamd_layerscale_bwd_launch(const bf16_t* dout, const bf16_t* z, const float* gamma, const float* keep, bf16_t* dz,
+                                float* part, long long rows, int C, long long rows_per_image, hipStream_t s);
 int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
                                         int njobs, hipStream_t s);
 
@@ -466,6 +476,71 @@ int icamd_strided_rows_copy(const void* src, long long src_stride, void* dst, lo
 int icamd_fill_zero(void* ptr, size_t bytes, void* stream) {
   if (ptr == nullptr) return ICAMD_ERR_BAD_ARG;
   return hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream) == hipSuccess ? ICAMD_OK : ICAMD_ERR_LAUNCH;
+}
+
+// ---- ConvNeXt: depthwise 7x7 + layer scale / stochastic depth / residual ------------------------------------------
+int icamd_dwconv7_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
+  if (x == nullptr || w == nullptr || y == nullptr || N <= 0 || H <= 0 || W <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_dwconv7_launch((const bf16_t*)x, (const bf16_t*)w, bias, nullptr, (bf16_t*)y, N, H, W, C, 0, (hipStream_t)stream);
+}
+
+int icamd_dwconv7_dgrad(const void* dy, const void* w, const void* addend, void* dx, int N, int H, int W, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
+  if (dy == nullptr || w == nullptr || dx == nullptr || N <= 0 || H <= 0 || W <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_dwconv7_launch((const bf16_t*)dy, (const bf16_t*)w, nullptr, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, 1,
+                              (hipStream_t)stream);
+}
+
+size_t icamd_dwconv7_wgrad_workspace_bytes(int N, int H, int W, int C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0) return 0;
+  return (size_t)icamd_dwconv7_wgrad_blocks(N, H, W, C) * 49 * C * sizeof(float);
+}
+
+int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                        int N, int H, int W, int C, void* stream) {
+  ProfScope _prof(PC_POOL, stream);
+  if (x == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
+  const size_t need = icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C);
+  if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  return icamd_dwconv7_wgrad_launch((const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, dw, N, H, W, C, accumulate,
+                                    (hipStream_t)stream);
+}
+
+int icamd_layerscale_fwd(const void* z, const void* inp, const float* gamma, const float* keep, void* out, long long rows, int C,
+                         long long rows_per_image, void* stream) {
+  ProfScope _prof(PC_BN_APPLY, stream);
+  if (z == nullptr || inp == nullptr || gamma == nullptr || out == nullptr || rows <= 0 || C <= 0 || rows_per_image <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_layerscale_fwd_launch((const bf16_t*)z, (const bf16_t*)inp, gamma, keep, (bf16_t*)out, rows, C, rows_per_image,
+                                     (hipStream_t)stream);
+}
+
+size_t icamd_layerscale_bwd_workspace_bytes(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return bn_chunk_bytes(C) + align_up((size_t)icamd_layerscale_bwd_blocks(rows) * 2 * C * sizeof(float), 256) +
+         align_up((size_t)3 * C * sizeof(float), 256);
+}
+
+int icamd_layerscale_bwd(const void* dout, const void* z, const float* gamma, const float* keep, void* dz, float* dgamma,
+                         long long rows, int C, long long rows_per_image, int accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (dout == nullptr || z == nullptr || gamma == nullptr || dz == nullptr || dgamma == nullptr || workspace == nullptr ||
+      rows <= 0 || C <= 0 || C > 4096 || rows_per_image <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < icamd_layerscale_bwd_workspace_bytes(rows, C)) return ICAMD_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(C);
+  float* part = (float*)ws;
+  const int nblk = icamd_layerscale_bwd_blocks(rows);
+  ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
+  float* scratch = (float*)ws;
+  int rc = icamd_layerscale_bwd_launch((const bf16_t*)dout, (const bf16_t*)z, gamma, keep, (bf16_t*)dz, part, rows, C,
+                                       rows_per_image, (hipStream_t)stream);
+  if (rc) return rc;
+  return icamd_sum_partials_launch(part, nblk, C, dgamma, scratch, accumulate, chunks, scratch + C, (hipStream_t)stream);
 }
 
 // ---- attention (ViT) --------------------------------------------------------------------------------------------

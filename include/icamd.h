@@ -134,6 +134,25 @@ size_t icamd_colsum_rows_workspace_bytes(long long rows, int cols);   /* zero-fi
 int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* out, int accumulate, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ---- ConvNeXt block pieces (/root/reference/semantic_segmentation/backbone/convnext.py:21-56; timm convnext_tiny
+ *      under train.py:194).  Depthwise 7x7 pad 3: x, y NHWC bf16 [N,H,W,C] (C % 32 == 0), w bf16 [7][7][C] (tap-major
+ *      shadow of the [C,1,7,7] parameter), bias fp32 [C]. ---------------------------------------------------------- */
+int icamd_dwconv7_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int C, void* stream);
+/* dx = depthwise-conv-transpose(dy, w) (+ addend: the residual branch's gradient) */
+int icamd_dwconv7_dgrad(const void* dy, const void* w, const void* addend, void* dx, int N, int H, int W, int C, void* stream);
+size_t icamd_dwconv7_wgrad_workspace_bytes(int N, int H, int W, int C);
+/* dw fp32 [7][7][C] (+)= sum over pixels dy * shifted x */
+int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                        int N, int H, int W, int C, void* stream);
+/* out = inp + keep[sample] * gamma[c] * z  (layer scale + stochastic depth + residual; keep NULL = 1; rows_per_image
+ * rows of C channels per sample).  bwd: dz = dout*keep*gamma, dgamma (+)= sum dout*z*keep (workspace zero-filled once). */
+int icamd_layerscale_fwd(const void* z, const void* inp, const float* gamma, const float* keep, void* out, long long rows, int C,
+                         long long rows_per_image, void* stream);
+size_t icamd_layerscale_bwd_workspace_bytes(long long rows, int C);
+int icamd_layerscale_bwd(const void* dout, const void* z, const float* gamma, const float* keep, void* dz, float* dgamma,
+                         long long rows, int C, long long rows_per_image, int accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ViT token plumbing: tokens[b][0] = cls + pos[0], tokens[b][1+i] = patches[b][i] + pos[1+i] (bf16 out, fp32 parameters);
  * batch_sum: out[j] (+)= sum_b x[b*stride + j] (cls_token / pos_embed gradients); strided row copies; zero fill. */
 int icamd_vit_tokens_fwd(const void* patches, const float* cls_token, const float* pos_embed, void* tokens, int B, int T, int C,

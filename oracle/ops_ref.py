@@ -278,3 +278,33 @@ def attention_bwd(qkv, dout, B, T, H, D, scale):
     o = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1) @ v
     o.permute(0, 2, 1, 3).reshape(B * T, H * D).backward(dout.float())
     return bf16_round(x.grad)
+
+
+# ---- ConvNeXt pieces ------------------------------------------------------------------------------------------------
+def dwconv7_fwd(x_nhwc, w_c77, bias):
+    """x [N,H,W,C], w [C,7,7] (torch depthwise layout), bias [C]. Returns y NHWC on the bf16 grid."""
+    C = x_nhwc.shape[-1]
+    y = F.conv2d(nhwc_to_nchw(x_nhwc.float()), w_c77.float().reshape(C, 1, 7, 7), bias.float(), padding=3, groups=C)
+    return bf16_round(nchw_to_nhwc(y))
+
+
+def dwconv7_bwd(x_nhwc, w_c77, dy_nhwc, addend=None):
+    C = x_nhwc.shape[-1]
+    x = nhwc_to_nchw(x_nhwc.float()).requires_grad_(True)
+    w = w_c77.float().reshape(C, 1, 7, 7).clone().requires_grad_(True)
+    F.conv2d(x, w, None, padding=3, groups=C).backward(nhwc_to_nchw(dy_nhwc.float()))
+    dx = nchw_to_nhwc(x.grad)
+    if addend is not None:
+        dx = dx + addend.float()
+    return bf16_round(dx), w.grad.reshape(C, 7, 7)
+
+
+def layerscale_fwd(z, inp, gamma, keep):
+    k = 1.0 if keep is None else keep.float().reshape(-1, *([1] * (z.dim() - 1)))
+    return bf16_round(inp.float() + k * gamma.float() * z.float())
+
+
+def layerscale_bwd(dout, z, gamma, keep):
+    k = 1.0 if keep is None else keep.float().reshape(-1, *([1] * (z.dim() - 1)))
+    d = dout.float() * k
+    return bf16_round(d * gamma.float()), (d * z.float()).reshape(-1, z.shape[-1]).double().sum(0).float()

@@ -642,3 +642,67 @@ def test_attention_fwd_bwd(lib, B, T, H):
     assert torch.isfinite(gd).all()
     for name, sl in (("dq", slice(0, H * D)), ("dk", slice(H * D, 2 * H * D)), ("dv", slice(2 * H * D, 3 * H * D))):
         assert R.rel_l2(gd[:, sl], rd[:, sl]) <= 6e-3, name      # P, dS pass through bf16 MFMA operands
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96)])
+def test_dwconv7_fwd_dgrad_wgrad(lib, shape):
+    hip = _hip()
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(130)
+    x = rnd_bf16(N, H, W, C, seed=131)
+    w = R.bf16_round(torch.randn(C, 7, 7, generator=g) * 0.15)
+    bias = torch.randn(C, generator=g) * 0.1
+    ry = R.dwconv7_fwd(x, w, bias)
+    xd = to_dev_bf16(x)
+    wd = to_dev_bf16(w.permute(1, 2, 0).contiguous())          # kernel layout [7][7][C]
+    bd = bias.to(DEV)
+    y = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib.icamd_dwconv7_fwd(hip.ptr(xd), hip.ptr(wd), hip.ptr(bd), hip.ptr(y), N, H, W, C, hip.stream_ptr()) == 0
+    sync()
+    got = y.float().cpu()
+    assert R.rel_l2(got, ry) <= 1e-3 and R.bf16_close(got, ry)
+    dy = rnd_bf16(N, H, W, C, seed=132)
+    addend = rnd_bf16(N, H, W, C, seed=133)
+    rdx, rdw = R.dwconv7_bwd(x, w, dy, addend)
+    dyd, ad = to_dev_bf16(dy), to_dev_bf16(addend)
+    dx = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib.icamd_dwconv7_dgrad(hip.ptr(dyd), hip.ptr(wd), hip.ptr(ad), hip.ptr(dx), N, H, W, C, hip.stream_ptr()) == 0
+    wsb = lib.icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dw = torch.full((7, 7, C), 1.0, device=DEV)
+    assert lib.icamd_dwconv7_wgrad(hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw), 1, hip.ptr(ws), wsb, N, H, W, C,
+                                   hip.stream_ptr()) == 0
+    sync()
+    assert R.rel_l2(dx.float().cpu(), rdx) <= 1e-3 and R.bf16_close(dx.float().cpu(), rdx)
+    assert R.rel_l2(dw.cpu(), 1.0 + rdw.permute(1, 2, 0)) <= 1e-4
+
+
+@pytest.mark.parametrize("use_keep", [False, True])
+def test_layerscale_residual_droppath(lib, use_keep):
+    hip = _hip()
+    N, HW, C = 6, 49, 192
+    g = torch.Generator().manual_seed(140)
+    z = rnd_bf16(N, HW, C, seed=141)
+    inp = rnd_bf16(N, HW, C, seed=142)
+    gamma = torch.randn(C, generator=g) * 0.5
+    keep = (torch.rand(N, generator=g) > 0.3).float() / 0.7 if use_keep else None
+    ro = R.layerscale_fwd(z, inp, gamma, keep)
+    zd, ind, gd = to_dev_bf16(z), to_dev_bf16(inp), gamma.to(DEV)
+    kd = keep.to(DEV) if use_keep else None
+    out = torch.empty(N, HW, C, dtype=torch.bfloat16, device=DEV)
+    assert lib.icamd_layerscale_fwd(hip.ptr(zd), hip.ptr(ind), hip.ptr(gd), hip.ptr(kd), hip.ptr(out), N * HW, C, HW,
+                                    hip.stream_ptr()) == 0
+    sync()
+    assert R.max_bf16_ulp(out.float().cpu(), ro) <= 1.0
+    dout = rnd_bf16(N, HW, C, seed=143)
+    rdz, rdg = R.layerscale_bwd(dout, z, gamma, keep)
+    wsb = lib.icamd_layerscale_bwd_workspace_bytes(N * HW, C)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    dz = torch.empty_like(out)
+    dg = torch.zeros(C, device=DEV)
+    dd = to_dev_bf16(dout)
+    assert lib.icamd_layerscale_bwd(hip.ptr(dd), hip.ptr(zd), hip.ptr(gd), hip.ptr(kd), hip.ptr(dz), hip.ptr(dg), N * HW, C, HW,
+                                    0, hip.ptr(ws), wsb, hip.stream_ptr()) == 0
+    sync()
+    assert R.max_bf16_ulp(dz.float().cpu(), rdz) <= 1.0
+    assert R.rel_l2(dg.cpu(), rdg) <= 1e-4
