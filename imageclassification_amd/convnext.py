@@ -1,0 +1,459 @@
+"""ConvNeXt (timm `convnext_tiny` family) on the gfx950 kernels: hand-written forward and backward.
+
+BASELINE.json configs[4] is ConvNeXt-T + mixup/cutmix + EMA.  The block is specified in the reference tree
+(/root/reference/semantic_segmentation/backbone/convnext.py:21-56: dwconv 7x7 -> LayerNorm -> Linear 4x -> GELU ->
+Linear -> gamma -> drop_path -> residual; stem 4x4/4 conv + channels-first LN :79-82; downsample LN + 2x2/2 conv
+:85-88; layer-scale init 1e-6 :32,39); the classification model itself comes from timm (train.py:194), whose parameter
+names are used here: `stem.{0,1}`, `stages.S.downsample.{0,1}`, `stages.S.blocks.B.{conv_dw,norm,mlp.fc1,mlp.fc2,gamma}`,
+`head.{norm,fc}`.  Stochastic depth follows timm: linearly increasing rates up to `drop_path_rate`
+(train.py:189-192 passes --drop_path, default 0.05), per-sample masks drawn on the host from torch's RNG.
+
+NHWC activations make every "channels-first LayerNorm" an ordinary row LayerNorm over pixels, and every Linear a 1x1
+convolution on the same tensor (bias fused); the depthwise stencil and the layer-scale tail are dedicated kernels.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+from .vit import _P, _align
+
+LN_EPS = 1e-6
+
+CONFIGS = {
+    "convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)),
+    "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
+    "convnext_test": ((1, 1, 2, 1), (32, 64, 96, 128)),   # small configuration for parity tests
+}
+
+
+class _Conv:
+    def __init__(self, name, cin, cout, k, stride, cin_p=None, cout_p=None):
+        self.name, self.cin, self.cout, self.k, self.stride = name, cin, cout, k, stride
+        self.cin_p, self.cout_p = cin_p or cin, cout_p or cout
+        self.w = self.b = None
+        self.wt_offset = None
+        self.descs = {}
+
+    def desc(self, N, H, W):
+        key = (N, H, W)
+        d = self.descs.get(key)
+        if d is None:
+            d = hip.conv_desc(N, H, W, self.cin_p, self.cout_p, self.k, self.k, self.stride, 0)
+            self.descs[key] = d
+        return d
+
+
+class ConvNeXt:
+    def __init__(self, arch="convnext_tiny", num_classes=1000, device="cuda", drop_path_rate=0.0, seed=None):
+        hip.require_gpu()
+        self.lib = hip.load()
+        self.arch, self.num_classes = arch, num_classes
+        self.device = torch.device(device)
+        self.training = True
+        self.depths, self.dims = CONFIGS[arch]
+        self.drop_path_rate = drop_path_rate
+        self.ncls_p = _align(num_classes, 64)
+        self.num_batches_tracked = 0
+        self.grad_ready_hook = None
+        self.injected_keep = None     # tests: list of per-block keep tensors (float [B]) to use instead of drawing
+        self._ws = {}
+        self._build()
+        self.init_weights(seed)
+
+    # ------------------------------------------------------------------ structure / arenas
+    def _build(self):
+        dev = self.device
+        self.params = OrderedDict()
+        off = 0
+
+        def add(name, torch_shape, kind, padded_shape):
+            nonlocal off
+            numel = 1
+            for s in padded_shape:
+                numel *= s
+            p = _P(name, off, numel, tuple(torch_shape), kind, tuple(padded_shape))
+            self.params[name] = p
+            off = _align(off + numel, 64)
+            return p
+
+        self.gemms = []   # layers that need a transposed shadow (data gradient)
+
+        def conv(name, cin, cout, k, stride, cin_p=None, cout_p=None, needs_dgrad=True, lin=False):
+            c = _Conv(name, cin, cout, k, stride, cin_p, cout_p)
+            if lin:
+                c.w = add(name + ".weight", (cout, cin), "lin", (c.cout_p, cin))
+            else:
+                c.w = add(name + ".weight", (cout, cin, k, k), "conv", (c.cout_p, k, k, c.cin_p))
+            c.b = add(name + ".bias", (cout,), "vec", (c.cout_p,))
+            if needs_dgrad:
+                self.gemms.append(c)
+            return c
+
+        d0 = self.dims[0]
+        self.stem = conv("stem.0", 3, d0, 4, 4, cin_p=8, needs_dgrad=False)
+        self.stem_nw = add("stem.1.weight", (d0,), "vec", (d0,))
+        self.stem_nb = add("stem.1.bias", (d0,), "vec", (d0,))
+        self.stages = []
+        rates = torch.linspace(0, self.drop_path_rate, sum(self.depths)).tolist()
+        bi = 0
+        for si, (depth, dim) in enumerate(zip(self.depths, self.dims)):
+            st = {"dim": dim, "blocks": []}
+            if si > 0:
+                prev = self.dims[si - 1]
+                st["ds_nw"] = add(f"stages.{si}.downsample.0.weight", (prev,), "vec", (prev,))
+                st["ds_nb"] = add(f"stages.{si}.downsample.0.bias", (prev,), "vec", (prev,))
+                st["ds"] = conv(f"stages.{si}.downsample.1", prev, dim, 2, 2)
+            for j in range(depth):
+                n = f"stages.{si}.blocks.{j}"
+                blk = {"name": n, "rate": rates[bi]}
+                blk["dw_w"] = add(f"{n}.conv_dw.weight", (dim, 1, 7, 7), "dw", (7, 7, dim))
+                blk["dw_b"] = add(f"{n}.conv_dw.bias", (dim,), "vec", (dim,))
+                blk["nw"] = add(f"{n}.norm.weight", (dim,), "vec", (dim,))
+                blk["nb"] = add(f"{n}.norm.bias", (dim,), "vec", (dim,))
+                blk["fc1"] = conv(f"{n}.mlp.fc1", dim, 4 * dim, 1, 1, lin=True)
+                blk["fc2"] = conv(f"{n}.mlp.fc2", 4 * dim, dim, 1, 1, lin=True)
+                blk["gamma"] = add(f"{n}.gamma", (dim,), "vec", (dim,))
+                st["blocks"].append(blk)
+                bi += 1
+            self.stages.append(st)
+        dl = self.dims[-1]
+        self.head_nw = add("head.norm.weight", (dl,), "vec", (dl,))
+        self.head_nb = add("head.norm.bias", (dl,), "vec", (dl,))
+        self.head = conv("head.fc", dl, self.num_classes, 1, 1, cout_p=self.ncls_p, lin=True)
+        self.n_params = off
+        self.param_arena = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad_arena = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        self.buffer_arena = torch.zeros(64, dtype=torch.float32, device=dev)
+        toff, descs, tjobs, jobs = 0, [], [], []
+        for c in self.gemms:
+            c.wt_offset = toff
+            T = c.k * c.k
+            descs.append([c.w.offset, toff, c.cout_p, T, c.cin_p, 0, 0, 0])
+            if c.cout_p % 64 == 0 and c.cin_p % 64 == 0:
+                tjobs += [[len(descs) - 1, t, a, b] for t in range(T) for a in range(0, c.cout_p, 64)
+                          for b in range(0, c.cin_p, 64)]
+            else:
+                jobs += [[len(descs) - 1, s] for s in range(0, c.w.numel, 4096)]
+            toff = _align(toff + c.w.numel, 128)
+        self.shadow_t = torch.zeros(toff, dtype=torch.bfloat16, device=dev)
+        self._tr_descs = torch.tensor(descs, dtype=torch.int64, device=dev)
+        self._tr_tjobs = torch.tensor(tjobs if tjobs else [[0, 0, 0, 0]], dtype=torch.int32, device=dev)
+        self._tr_ntjobs = len(tjobs)
+        self._tr_jobs = torch.tensor(jobs if jobs else [[0, 0]], dtype=torch.int32, device=dev)
+        self._tr_njobs = len(jobs)
+
+    def init_weights(self, seed=None):
+        """timm ConvNeXt init: trunc_normal(std .02) conv / linear weights, zero biases, LayerNorm 1 / 0, gamma 1e-6."""
+        g = torch.Generator()
+        g.manual_seed(seed if seed is not None else torch.initial_seed() % (2 ** 63))
+        sd = OrderedDict()
+        for name, p in self.params.items():
+            if p.kind in ("conv", "lin", "dw"):
+                sd[name] = torch.nn.init.trunc_normal_(torch.empty(p.torch_shape), std=0.02, generator=g)
+            elif name.endswith(".gamma"):
+                sd[name] = torch.full(p.torch_shape, 1e-6)
+            elif name.endswith("weight"):
+                sd[name] = torch.ones(p.torch_shape)
+            else:
+                sd[name] = torch.zeros(p.torch_shape)
+        self.load_state_dict(sd)
+
+    def _to_arena(self, p, t):
+        t = t.detach().to(torch.float32).cpu()
+        full = torch.zeros(p.padded_shape)
+        if p.kind == "conv":
+            full[: t.shape[0], :, :, : t.shape[1]] = t.permute(0, 2, 3, 1)
+        elif p.kind == "lin":
+            full[: t.shape[0], :] = t.reshape(t.shape[0], -1)
+        elif p.kind == "dw":
+            full[:] = t.reshape(t.shape[0], 7, 7).permute(1, 2, 0)
+        else:
+            full.view(-1)[: t.numel()] = t.flatten()
+        return full.flatten()
+
+    def _from_arena(self, p, flat):
+        t = flat.reshape(p.padded_shape)
+        if p.kind == "conv":
+            return t[: p.torch_shape[0], :, :, : p.torch_shape[1]].permute(0, 3, 1, 2).contiguous()
+        if p.kind == "lin":
+            return t[: p.torch_shape[0], :].clone()
+        if p.kind == "dw":
+            return t.permute(2, 0, 1).reshape(p.torch_shape).contiguous()
+        return t.flatten()[: p.torch_shape[0]].clone()
+
+    def load_state_dict(self, sd, strict=True):
+        host = self.param_arena.cpu()
+        missing = [n for n in self.params if n not in sd]
+        if strict and missing:
+            raise KeyError(f"missing keys in state_dict: {missing[:5]}")
+        for name, p in self.params.items():
+            if name in sd:
+                host[p.offset:p.offset + p.numel] = self._to_arena(p, sd[name])
+        self.param_arena.copy_(host)
+        self.refresh_shadow()
+        return missing
+
+    def state_dict(self):
+        host = self.param_arena.cpu()
+        return OrderedDict((n, self._from_arena(p, host[p.offset:p.offset + p.numel])) for n, p in self.params.items())
+
+    def named_parameters(self):
+        for name, p in self.params.items():
+            yield name, self.param_arena[p.offset:p.offset + p.numel]
+
+    def parameters(self):
+        for _, v in self.named_parameters():
+            yield v
+
+    def grad_of(self, name):
+        p = self.params[name]
+        return self._from_arena(p, self.grad_arena[p.offset:p.offset + p.numel].cpu())
+
+    def refresh_shadow(self):
+        hip.check(self.lib.icamd_f32_to_bf16(self.param_arena.data_ptr(), self.shadow.data_ptr(), self.n_params,
+                                             hip.stream_ptr()), "f32_to_bf16")
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        s = hip.stream_ptr()
+        if self._tr_ntjobs:
+            hip.check(self.lib.icamd_filter_transpose_tiled(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
+                                                            self._tr_descs.data_ptr(), self._tr_tjobs.data_ptr(),
+                                                            self._tr_ntjobs, s), "filter_transpose_tiled")
+        if self._tr_njobs:
+            hip.check(self.lib.icamd_filter_transpose(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
+                                                      self._tr_descs.data_ptr(), self._tr_jobs.data_ptr(), self._tr_njobs, s),
+                      "filter_transpose")
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, N, H, W):
+        key = (N, H, W)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev, lib = self.device, self.lib
+
+        def act(*shape):
+            return torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+
+        def f32(n):
+            return torch.empty(n, dtype=torch.float32, device=dev)
+
+        ws = {"N": N, "H": H, "W": W}
+        ws["x8"] = act(N, H, W, 8)
+        h, w = H // 4, W // 4
+        d0 = self.dims[0]
+        ws["s"] = act(N, h, w, d0)
+        ws["x0"] = act(N, h, w, d0)
+        ws["st_stem"] = f32(2 * N * h * w)
+        max_act, max_rows = N * h * w * 4 * d0, N * h * w
+        wg = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(self.stem.desc(N, H, W)))
+        dwg = 0
+        stages = []
+        for si, st in enumerate(self.stages):
+            dim = st["dim"]
+            sw = {"blocks": []}
+            if si > 0:
+                sw["ln"] = act(N, h, w, self.dims[si - 1])
+                sw["st"] = f32(2 * N * h * w)
+                wg = max(wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(st["ds"].desc(N, h, w))))
+                h, w = h // 2, w // 2
+                sw["x"] = act(N, h, w, dim)
+            sw["hw"] = (h, w)
+            rows = N * h * w
+            for blk in st["blocks"]:
+                sw["blocks"].append({"d": act(N, h, w, dim), "h": act(N, h, w, dim), "z1": act(N, h, w, 4 * dim),
+                                     "a": act(N, h, w, 4 * dim), "z2": act(N, h, w, dim), "out": act(N, h, w, dim),
+                                     "st": f32(2 * rows), "keep": None})
+                wg = max(wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(blk["fc1"].desc(N, h, w))),
+                         lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(blk["fc2"].desc(N, h, w))))
+                dwg = max(dwg, lib.icamd_dwconv7_wgrad_workspace_bytes(N, h, w, dim))
+                max_act = max(max_act, rows * 4 * dim)
+            stages.append(sw)
+        ws["stages"] = stages
+        ws["final_hw"] = (h, w)
+        dl = self.dims[-1]
+        ws["pool"] = act(N, dl)
+        ws["pn"] = act(N, dl)
+        ws["st_head"] = f32(2 * N)
+        ws["logits"] = torch.zeros(N, self.ncls_p, dtype=torch.bfloat16, device=dev)
+        ws["dlogits"] = torch.zeros(N, self.ncls_p, dtype=torch.bfloat16, device=dev)
+        ws["loss_rows"] = f32(N)
+        ws["pred"] = torch.empty(N, dtype=torch.int32, device=dev)
+        wg = max(wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(self.head.desc(N, 1, 1))))
+        ws["wg_ws"] = torch.empty(wg, dtype=torch.uint8, device=dev)
+        ws["wg_bytes"] = wg
+        ws["dwg_ws"] = torch.empty(max(dwg, 256), dtype=torch.uint8, device=dev)
+        ws["dwg_bytes"] = dwg
+        maxc = 4 * max(self.dims)
+        ws["ln_bytes"] = max(lib.icamd_layernorm_bwd_workspace_bytes(max_rows, c) for c in self.dims)
+        ws["ln_ws"] = torch.zeros(ws["ln_bytes"], dtype=torch.uint8, device=dev)
+        ws["cs_bytes"] = max(lib.icamd_colsum_rows_workspace_bytes(max_rows, min(maxc, 4096)),
+                             lib.icamd_layerscale_bwd_workspace_bytes(max_rows, max(self.dims)))
+        ws["cs_ws"] = torch.zeros(ws["cs_bytes"], dtype=torch.uint8, device=dev)
+        ws["max_act"] = max_act
+        self._ws[key] = ws
+        return ws
+
+    def _scratch(self, ws):
+        if "g" not in ws:
+            ws["g"] = [torch.empty(ws["max_act"], dtype=torch.bfloat16, device=self.device) for _ in range(5)]
+        return ws["g"]
+
+    # ------------------------------------------------------------------ helpers
+    def _pf(self, p):
+        return self.param_arena.data_ptr() + 4 * p.offset
+
+    def _gf(self, p):
+        return self.grad_arena.data_ptr() + 4 * p.offset
+
+    def _w(self, c):
+        return self.shadow.data_ptr() + 2 * c.w.offset
+
+    def _wt(self, c):
+        return self.shadow_t.data_ptr() + 2 * c.wt_offset
+
+    def pack(self, x_nchw, mix=None):
+        N, C, H, W = x_nchw.shape
+        ws = self._workspace(N, H, W)
+        mode, lam, box = (0, 1.0, (0, 0, 0, 0)) if mix is None else mix
+        hip.check(self.lib.icamd_pack_input(x_nchw.data_ptr(), ws["x8"].data_ptr(), N, C, H, W, mode, float(lam), int(box[0]),
+                                            int(box[1]), int(box[2]), int(box[3]), hip.stream_ptr()), "pack")
+        return ws
+
+    def _conv(self, c, x_ptr, y, N, H, W, s):
+        hip.check(self.lib.icamd_conv2d_fwd(ctypes.byref(c.desc(N, H, W)), x_ptr, self._w(c), y.data_ptr(), self._pf(c.b), None,
+                                            None, s), c.name)
+
+    def _ln(self, x, wp, bp, y, st, rows, C, s):
+        hip.check(self.lib.icamd_layernorm_fwd(x.data_ptr(), self._pf(wp), self._pf(bp), y.data_ptr(), st.data_ptr(),
+                                               st.data_ptr() + 4 * rows, rows, C, LN_EPS, s), wp.name)
+
+    # ------------------------------------------------------------------ forward
+    def forward_packed(self, ws):
+        lib, s = self.lib, hip.stream_ptr()
+        N, H, W = ws["N"], ws["H"], ws["W"]
+        self._conv(self.stem, ws["x8"].data_ptr(), ws["s"], N, H, W, s)
+        h, w = H // 4, W // 4
+        self._ln(ws["s"], self.stem_nw, self.stem_nb, ws["x0"], ws["st_stem"], N * h * w, self.dims[0], s)
+        x = ws["x0"]
+        bi = 0
+        for si, (st, sw) in enumerate(zip(self.stages, ws["stages"])):
+            dim = st["dim"]
+            if si > 0:
+                sw["in"] = x
+                self._ln(x, st["ds_nw"], st["ds_nb"], sw["ln"], sw["st"], N * h * w, self.dims[si - 1], s)
+                self._conv(st["ds"], sw["ln"].data_ptr(), sw["x"], N, h, w, s)
+                h, w = h // 2, w // 2
+                x = sw["x"]
+            rows = N * h * w
+            for blk, b in zip(st["blocks"], sw["blocks"]):
+                b["in"] = x
+                hip.check(lib.icamd_dwconv7_fwd(x.data_ptr(), self.shadow.data_ptr() + 2 * blk["dw_w"].offset,
+                                                self._pf(blk["dw_b"]), b["d"].data_ptr(), N, h, w, dim, s), blk["name"] + " dw")
+                self._ln(b["d"], blk["nw"], blk["nb"], b["h"], b["st"], rows, dim, s)
+                self._conv(blk["fc1"], b["h"].data_ptr(), b["z1"], N, h, w, s)
+                hip.check(lib.icamd_gelu_fwd(b["z1"].data_ptr(), b["a"].data_ptr(), b["z1"].numel(), s), "gelu")
+                self._conv(blk["fc2"], b["a"].data_ptr(), b["z2"], N, h, w, s)
+                keep = None
+                if self.training and blk["rate"] > 0.0:
+                    if self.injected_keep is not None:
+                        keep = self.injected_keep[bi].to(self.device, dtype=torch.float32)
+                    else:
+                        kp = 1.0 - blk["rate"]
+                        keep = (torch.rand(N) < kp).float().div_(kp).to(self.device)   # timm drop_path: per sample, scaled
+                b["keep"] = keep
+                hip.check(lib.icamd_layerscale_fwd(b["z2"].data_ptr(), x.data_ptr(), self._pf(blk["gamma"]),
+                                                   None if keep is None else keep.data_ptr(), b["out"].data_ptr(), rows, dim,
+                                                   h * w, s), "layer scale")
+                x = b["out"]
+                bi += 1
+        dl = self.dims[-1]
+        hip.check(lib.icamd_avgpool_fwd(x.data_ptr(), ws["pool"].data_ptr(), N, h * w, dl, s), "avgpool")
+        self._ln(ws["pool"], self.head_nw, self.head_nb, ws["pn"], ws["st_head"], N, dl, s)
+        self._conv(self.head, ws["pn"].data_ptr(), ws["logits"], N, 1, 1, s)
+        return ws["logits"]
+
+    def __call__(self, x_nchw):
+        ws = self.pack(x_nchw.to(self.device, dtype=torch.float32).contiguous())
+        return self.forward_packed(ws)[:, : self.num_classes]
+
+    # ------------------------------------------------------------------ backward
+    def backward_packed(self, ws, accumulate=False):
+        lib, s = self.lib, hip.stream_ptr()
+        N = ws["N"]
+        acc = int(bool(accumulate))
+        hook = self.grad_ready_hook
+        wsp, wsb = ws["wg_ws"].data_ptr(), ws["wg_bytes"]
+        dwp, dwb = ws["dwg_ws"].data_ptr(), ws["dwg_bytes"]
+        lnp, lnb = ws["ln_ws"].data_ptr(), ws["ln_bytes"]
+        csp, csb = ws["cs_ws"].data_ptr(), ws["cs_bytes"]
+        G = [g.data_ptr() for g in self._scratch(ws)]
+
+        def gemm_bwd(c, x_ptr, dy_ptr, n, h, w, dx_ptr):
+            d = c.desc(n, h, w)
+            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(c.w), acc, wsp, wsb, s), c.name + " wgrad")
+            hip.check(lib.icamd_colsum_rows(dy_ptr, n * d.OH * d.OW, c.cout_p, c.cout_p, self._gf(c.b), acc, csp, csb, s),
+                      c.name + " bias grad")
+            if dx_ptr is not None:
+                hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(c), dx_ptr, None, None, s), c.name + " dgrad")
+
+        def ln_bwd(dy_ptr, x, st, wp, bp, dx_ptr, rows, C):
+            hip.check(lib.icamd_layernorm_bwd(dy_ptr, x.data_ptr(), st.data_ptr(), st.data_ptr() + 4 * rows, self._pf(wp), None,
+                                              dx_ptr, self._gf(wp), self._gf(bp), rows, C, acc, lnp, lnb, s), wp.name + " bwd")
+
+        dl = self.dims[-1]
+        h, w = ws["final_hw"]
+        gemm_bwd(self.head, ws["pn"].data_ptr(), ws["dlogits"].data_ptr(), N, 1, 1, G[1])
+        ln_bwd(G[1], ws["pool"], ws["st_head"], self.head_nw, self.head_nb, G[2], N, dl)
+        dout = G[0]
+        hip.check(lib.icamd_avgpool_bwd(G[2], dout, N, h * w, dl, s), "avgpool bwd")
+        if hook:
+            hook(self.head_nw.offset, self.n_params)
+        other = G[3]
+        for si in range(len(self.stages) - 1, -1, -1):
+            st, sw = self.stages[si], ws["stages"][si]
+            dim = st["dim"]
+            rows = N * h * w
+            for blk, b in zip(reversed(st["blocks"]), reversed(sw["blocks"])):
+                keep = None if b["keep"] is None else b["keep"].data_ptr()
+                hip.check(lib.icamd_layerscale_bwd(dout, b["z2"].data_ptr(), self._pf(blk["gamma"]), keep, G[1],
+                                                   self._gf(blk["gamma"]), rows, dim, h * w, acc, csp, csb, s), "layer scale bwd")
+                gemm_bwd(blk["fc2"], b["a"].data_ptr(), G[1], N, h, w, G[2])                 # G2 = d a
+                hip.check(lib.icamd_gelu_bwd(G[2], b["z1"].data_ptr(), G[4], b["z1"].numel(), s), "gelu bwd")   # G4 = d z1
+                gemm_bwd(blk["fc1"], b["h"].data_ptr(), G[4], N, h, w, G[1])                 # G1 = d h
+                ln_bwd(G[1], b["d"], b["st"], blk["nw"], blk["nb"], G[2], rows, dim)         # G2 = d (dwconv out)
+                hip.check(lib.icamd_dwconv7_wgrad(b["in"].data_ptr(), G[2], self._gf(blk["dw_w"]), acc, dwp, dwb, N, h, w, dim, s),
+                          blk["name"] + " dw wgrad")
+                hip.check(lib.icamd_colsum_rows(G[2], rows, dim, dim, self._gf(blk["dw_b"]), acc, csp, csb, s), "dw bias grad")
+                hip.check(lib.icamd_dwconv7_dgrad(G[2], self.shadow.data_ptr() + 2 * blk["dw_w"].offset, dout, other, N, h, w, dim,
+                                                  s), blk["name"] + " dw dgrad")             # + residual gradient
+                dout, other = other, dout
+                if hook:
+                    hook(blk["dw_w"].offset, None)
+            if si > 0:
+                prev = self.dims[si - 1]
+                gemm_bwd(st["ds"], sw["ln"].data_ptr(), dout, N, 2 * h, 2 * w, G[1])
+                h, w = 2 * h, 2 * w
+                ln_bwd(G[1], sw["in"], sw["st"], st["ds_nw"], st["ds_nb"], other, N * h * w, prev)
+                dout, other = other, dout
+                if hook:
+                    hook(st["ds_nw"].offset, None)
+        ln_bwd(dout, ws["s"], ws["st_stem"], self.stem_nw, self.stem_nb, G[1], N * h * w, self.dims[0])
+        gemm_bwd(self.stem, ws["x8"].data_ptr(), G[1], N, ws["H"], ws["W"], None)
+        if hook:
+            hook(0, None)

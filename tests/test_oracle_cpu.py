@@ -102,6 +102,11 @@ def test_vit_oracle_parameter_count():
         assert k in names
 
 
+def test_convnext_oracle_parameter_count():
+    from oracle.convnext_ref import ConvNeXtRef
+    assert sum(p.numel() for p in ConvNeXtRef("convnext_tiny").parameters()) == 28589128
+
+
 def test_oracle_ops_agree_with_torch_primitives():
     g = torch.Generator().manual_seed(0)
     y = R.bf16_round(torch.randn(4, 5, 5, 16, generator=g))

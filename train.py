@@ -25,6 +25,7 @@ from imageclassification_amd.engine import evaluate, train_one_epoch
 from imageclassification_amd.mixup import CrossEntropyLoss, LabelSmoothingCrossEntropy, Mixup, SoftTargetCrossEntropy
 from imageclassification_amd.nets import ARCHS, ResNet
 from imageclassification_amd.vit import CONFIGS as VIT_CONFIGS, VisionTransformer
+from imageclassification_amd.convnext import CONFIGS as CNX_CONFIGS, ConvNeXt
 from imageclassification_amd.optim_factory import create_optimizer
 from imageclassification_amd.utils import NativeScalerWithGradNormCount as NativeScaler
 
@@ -73,12 +74,14 @@ def get_args_parser():
     return p
 
 
-def create_model(name, num_classes, input_size=224):
+def create_model(name, num_classes, input_size=224, drop_path=0.0):
     if name in ARCHS:
         return ResNet(name, num_classes)
     if name in VIT_CONFIGS:
         return VisionTransformer(name, num_classes, img_size=input_size)
-    raise ValueError(f"model '{name}' is not built for the MI355X path yet (available: {sorted(ARCHS) + sorted(VIT_CONFIGS)})")
+    if name in CNX_CONFIGS:
+        return ConvNeXt(name, num_classes, drop_path_rate=drop_path)   # reference train.py:189-192
+    raise ValueError(f"model '{name}' is not built for the MI355X path yet (available: {sorted(ARCHS) + sorted(VIT_CONFIGS) + sorted(CNX_CONFIGS)})")
 
 
 def main(args):
@@ -113,7 +116,7 @@ def main(args):
                          prob=args.mixup_prob, switch_prob=args.mixup_switch_prob, mode=args.mixup_mode,
                          label_smoothing=args.smoothing, num_classes=num_classes)
 
-    model = create_model(args.model, num_classes, args.input_size)
+    model = create_model(args.model, num_classes, args.input_size, args.drop_path)
     model_ema = ModelEmaV3(model, decay=0.9995, device=device) if args.model_ema else None
     model_without_ddp = model
     n_parameters = sum(int(np.prod(p.torch_shape)) for p in model.params.values())
