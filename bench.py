@@ -63,6 +63,25 @@ def vit_flops_per_image(net):
     return layers
 
 
+def convnext_flops_per_image(net, hw):
+    """Algorithmic forward FLOPs of the GEMM-shaped layers (stem, downsample, pointwise MLPs, head); the depthwise
+    stencils (2*49 flop per output element) are listed separately as `dwconv`."""
+    layers, dw = [], 0
+    h = w = hw // 4
+    layers.append(("stem", 2 * h * w * net.dims[0] * 3 * 16))
+    for si, st in enumerate(net.stages):
+        dim = st["dim"]
+        if si > 0:
+            h, w = h // 2, w // 2
+            layers.append((f"stages.{si}.downsample", 2 * h * w * dim * net.dims[si - 1] * 4))
+        for blk in st["blocks"]:
+            layers.append((blk["name"] + ".mlp", 2 * 2 * h * w * dim * 4 * dim))
+            dw += 2 * 49 * h * w * dim
+    layers.append(("head", 2 * net.dims[-1] * net.num_classes))
+    layers.append(("dwconv", dw))
+    return layers
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -88,6 +107,7 @@ def main():
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mixup", action="store_true", help="mixup 0.8 + cutmix 1.0 + EMA (BASELINE configs[4] recipe)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -115,18 +135,33 @@ def main():
     from imageclassification_amd.engine import train_one_epoch
     from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
     from imageclassification_amd.nets import ARCHS, ResNet
-    from imageclassification_amd.vit import VisionTransformer
+    from imageclassification_amd.vit import CONFIGS as VIT_CONFIGS, VisionTransformer
+    from imageclassification_amd.convnext import CONFIGS as CNX_CONFIGS, ConvNeXt
+    from imageclassification_amd.ema import ModelEmaV3
+    from imageclassification_amd.mixup import Mixup, SoftTargetCrossEntropy
     from imageclassification_amd.optim_factory import create_optimizer
     from imageclassification_amd.utils import NativeScalerWithGradNormCount, cosine_scheduler
 
     lib = hip.load()
     C, B, HW = 1000, args.batch, args.hw
-    is_vit = args.arch not in ARCHS
-    net = VisionTransformer(args.arch, C, device=str(device), img_size=HW, seed=88) if is_vit else \
-        ResNet(args.arch, C, device=str(device), seed=88)
+    is_vit = args.arch in VIT_CONFIGS
+    is_cnx = args.arch in CNX_CONFIGS
+    if is_vit:
+        net = VisionTransformer(args.arch, C, device=str(device), img_size=HW, seed=88)
+    elif is_cnx:
+        net = ConvNeXt(args.arch, C, device=str(device), drop_path_rate=0.05, seed=88)   # reference --drop_path default
+    else:
+        net = ResNet(args.arch, C, device=str(device), seed=88)
     model = DistributedDataParallel(net) if world > 1 else net
     opt = create_optimizer("adamw", 1e-3, 5e-4, net)
     crit = LabelSmoothingCrossEntropy(0.1)
+    mixup_fn, model_ema = None, None
+    if args.mixup:   # BASELINE configs[4]: mixup 0.8 + cutmix 1.0 (soft targets) + model EMA 0.9995
+        import numpy as np
+        np.random.seed(88 + rank)
+        mixup_fn = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)
+        crit = SoftTargetCrossEntropy()
+        model_ema = ModelEmaV3(net, decay=0.9995)
     total_steps = args.warmup + args.steps
     sink = io.StringIO()
     with contextlib.redirect_stdout(sink):
@@ -140,7 +175,7 @@ def main():
     def run(nsteps, start):
         loader = [pool[i % len(pool)] for i in range(nsteps)]
         with contextlib.redirect_stdout(sink):
-            return train_one_epoch(model, crit, loader, opt, device, 0, NativeScalerWithGradNormCount(), None, None, None,
+            return train_one_epoch(model, crit, loader, opt, device, 0, NativeScalerWithGradNormCount(), None, model_ema, mixup_fn,
                                    start_steps=start, lr_schedule_values=lr, wd_schedule_values=wd,
                                    num_training_steps_per_epoch=nsteps, update_freq=1, use_amp=True, num_classes=C)
 
@@ -181,7 +216,8 @@ def main():
     psteps = prof_steps
 
     if rank == 0:
-        layers = vit_flops_per_image(net) if is_vit else conv_flops_per_image(net, HW)
+        layers = vit_flops_per_image(net) if is_vit else (convnext_flops_per_image(net, HW)[:-1] if is_cnx
+                                                           else conv_flops_per_image(net, HW))
         fwd_flops = sum(f for _, f in layers) * B           # per step, all conv/FC (and attention) forward launches
         stem_flops = layers[0][1] * B
         algo = {"conv_fwd": fwd_flops, "conv_dgrad": fwd_flops - stem_flops, "conv_wgrad": fwd_flops}
@@ -222,13 +258,15 @@ def main():
             cpu = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
                    "sample": f"{args.cpu_steps} steps of batch 32 (1 warm-up), torch-CPU fp32 restatement of engine.py "
                              f"train_one_epoch, {args.arch} {HW}x{HW}, AdamW+label smoothing"}
-        label = {"resnet50": "ResNet-50", "vit_base_patch16_224": "ViT-B/16"}.get(args.arch, args.arch)
+        label = {"resnet50": "ResNet-50", "vit_base_patch16_224": "ViT-B/16", "convnext_tiny": "ConvNeXt-T"}.get(args.arch, args.arch)
+        if args.mixup:
+            label += " + mixup/cutmix + EMA"
         out = {"metric": f"images/sec (whole node) {label} bf16 {HW}^2 training", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, "
-                                      f"label smoothing 0.1, 1000 classes (BASELINE configs[{3 if is_vit else (1 if world == 1 else 2)}])",
+                                      f"label smoothing 0.1, 1000 classes (BASELINE configs[{3 if is_vit else (4 if is_cnx else (1 if world == 1 else 2))}])",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
                "kernel_timing": {"method": "HIP events on the launch stream around every C-ABI call, separate pass",

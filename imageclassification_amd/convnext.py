@@ -25,7 +25,7 @@ LN_EPS = 1e-6
 CONFIGS = {
     "convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)),
     "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
-    "convnext_test": ((1, 1, 2, 1), (32, 64, 96, 128)),   # small configuration for parity tests
+    "convnext_test": ((1, 1, 2, 1), (32, 64, 128, 192)),   # small configuration for parity tests
 }
 
 

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from .resnet_ref import _RoundBF16, _RoundWeight
 
 CONFIGS = {"convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)), "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
-           "convnext_test": ((1, 1, 2, 1), (32, 64, 96, 128))}
+           "convnext_test": ((1, 1, 2, 1), (32, 64, 128, 192))}
 
 
 def _r(x, on):
