@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../include"
 OBJS=""
-for f in conv_igemm conv_wgrad norm_pool loss_optim token_ops attention dwconv capi; do
+for f in conv_igemm conv_wgrad norm_pool loss_optim token_ops attention dwconv gemm_nt capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ icamd_internal.h -nt build/$f.o ] || [ ../../include/icamd.h -nt build/$f.o ]; then
     mkdir -p build
     $HIPCC $FLAGS "$@" -c $f.hip -o build/$f.o &

@@ -152,6 +152,14 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
   ProfScope _prof(PC_IGEMM_FWD, stream);
   if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
   if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && stats == nullptr &&
+      icamd_gemm_nt_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
+    GemmNtParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.addend = (const bf16_t*)addend; g.bias = bias;
+    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
+    return icamd_gemm_nt_launch(g, (hipStream_t)stream);
+  }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w; p.out = (bf16_t*)y;
@@ -177,6 +185,14 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
   if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
+  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && addend_bits == nullptr && f == nullptr &&
+      icamd_gemm_nt_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {
+    GemmNtParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.addend = (const bf16_t*)addend;
+    g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout;
+    return icamd_gemm_nt_launch(g, (hipStream_t)stream);
+  }
   float* partials = f ? f->partials : nullptr;
   // one launch per output parity class (ph, pw): pixels h = st*p + ph, w = st*q + pw receive only the taps
   // r with (ph + pad - r) % st == 0, read at dy row p + (ph + pad - r)/st

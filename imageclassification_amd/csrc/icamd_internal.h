@@ -33,6 +33,20 @@ struct IgemmParams {
 int icamd_igemm_launch(IgemmParams& p, hipStream_t stream);
 int icamd_igemm_pick_bn(int Cout);
 
+// Dense NT GEMM for big pointwise problems: out[m][n] = sum_k A[m][k] * B[n][k] (+ bias[n]) (+ addend[m][n])
+struct GemmNtParams {
+  const bf16_t* A;       // [M][K]
+  const bf16_t* B;       // [N][K]
+  bf16_t* out;           // [M][N]
+  const bf16_t* addend;  // optional [M][N]
+  const float* bias;     // optional [N]
+  int M, N, K;
+  int ntiles_n;          // filled by the launcher
+};
+int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream);
+// true when the 256x256-tile kernel is expected to beat the 128x128 implicit-GEMM kernel for this problem
+bool icamd_gemm_nt_wanted(long long M, int N, int K);
+
 // Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
 struct WgradParams {
   const bf16_t* x;    // [N, IH, IW, Cin]

@@ -4,6 +4,7 @@ bf16 outputs are compared on the bf16 grid: relative L2 error <= 1e-3 (north_sta
 a 1-2 ulp spread elementwise (different fp32 accumulation order); fp32 outputs: rel L2 <= 1e-4/1e-3 as noted.
 """
 import ctypes
+import os
 
 import pytest
 import torch
@@ -130,6 +131,77 @@ def test_conv_dgrad(lib, case):
         assert torch.isfinite(got).all()
         assert R.rel_l2(got, ref) <= 1e-3
         assert R.bf16_close(got, ref)
+
+
+# Pointwise problems big enough for the 256x256-tile kernel (gemm_nt.hip): (N, H, W, Cin, Cout)
+LARGE_POINTWISE = [
+    (4, 64, 64, 256, 1024),     # exact tiles
+    (1, 129, 127, 288, 1000),   # ragged M and N, K = 9 stages
+    (2, 197, 64, 768, 2304),    # ViT qkv shape at a small batch
+]
+
+
+def _run_large_pointwise(lib, cases):
+    hip = _hip()
+    for (N, H, W, Cin, Cout) in cases:
+        d = hip.conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0)
+        x = rnd_bf16(N, H, W, Cin, seed=11)
+        w = rnd_bf16(Cout, 1, 1, Cin, scale=(1.0 / Cin) ** 0.5, seed=12)
+        bias = torch.randn(Cout, generator=torch.Generator().manual_seed(13))
+        addend = rnd_bf16(N, H, W, Cout, seed=14)
+        xd, wd = to_dev_bf16(x), to_dev_bf16(w)
+        for use_extra in (False, True):
+            ref = R.conv2d_fwd(x, w, 1, 0, bias if use_extra else None, addend if use_extra else None)
+            y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+            bd = bias.to(DEV) if use_extra else None
+            ad = to_dev_bf16(addend) if use_extra else None
+            rc = lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(xd), hip.ptr(wd), hip.ptr(y), hip.ptr(bd), hip.ptr(ad),
+                                      None, hip.stream_ptr())
+            assert rc == 0
+            sync()
+            got = y.float().cpu()
+            assert torch.isfinite(got).all()
+            assert R.rel_l2(got, ref) <= 1e-3
+            assert R.bf16_close(got, ref)
+        # data gradient of the same layer: dx[m][ci] = sum_co dy[m][co] w[co][ci] (+ addend)
+        dy = rnd_bf16(N, H, W, Cout, seed=15)
+        add_in = rnd_bf16(N, H, W, Cin, seed=16)
+        w_t = w.permute(3, 1, 2, 0).contiguous()
+        dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w_t)
+        for use_add in (False, True):
+            ref = R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in if use_add else None)
+            dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ad = to_dev_bf16(add_in) if use_add else None
+            rc = lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), None,
+                                        hip.stream_ptr())
+            assert rc == 0
+            sync()
+            got = dx.float().cpu()
+            assert torch.isfinite(got).all()
+            assert R.rel_l2(got, ref) <= 1e-3
+            assert R.bf16_close(got, ref)
+
+
+def test_pointwise_large_tile_gemm(lib):
+    _run_large_pointwise(lib, LARGE_POINTWISE)
+
+
+def test_pointwise_large_tile_gemm_forced_small_k():
+    """ICAMD_GEMM_NT=2 routes every eligible pointwise problem through gemm_nt.hip: covers 1-, 2- and 3-stage K loops and
+    tiles that are mostly padding.  The routing switch is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_kernels_gpu as T\n"
+        "from imageclassification_amd import hip\n"
+        "lib = hip.load()\n"
+        "T._run_large_pointwise(lib, [(1, 5, 7, 32, 40), (2, 9, 9, 64, 264), (1, 20, 20, 96, 512), (3, 16, 16, 160, 72)])\n"
+        "print('forced-ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ICAMD_GEMM_NT="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
 
 
 WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0)]
