@@ -28,14 +28,17 @@ PEAK_HBM_GBS = 8000.0
 
 def conv_flops_per_image(net, hw):
     """Algorithmic MACs*2 of every conv/FC forward at true (unpadded) channel counts."""
-    total = 0
     h = w = hw
     layers = []
+    layer_bytes = []
 
     def add(conv, ih, iw):
         oh = (ih + 2 * conv.pad - conv.k) // conv.stride + 1
         ow = (iw + 2 * conv.pad - conv.k) // conv.stride + 1
         layers.append((conv.name, 2 * oh * ow * conv.cout * conv.cin * conv.k * conv.k))
+        # algorithmic HBM bytes: bf16 input (stem: RGB stored zero-padded to 8 channels), bf16 output, filter elements
+        cin_mem = max(conv.cin, 8)
+        layer_bytes.append((2 * ih * iw * cin_mem, 2 * oh * ow * conv.cout, conv.cout * cin_mem * conv.k * conv.k))
         return oh, ow
 
     h, w = add(net.stem_conv, h, w)
@@ -48,6 +51,7 @@ def conv_flops_per_image(net, hw):
             ih, iw = add(conv, ih, iw)
         h, w = ih, iw
     add(net.fc, 1, 1)
+    conv_flops_per_image.layer_bytes = layer_bytes
     return layers
 
 
@@ -240,10 +244,27 @@ def main():
             traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in sel) / n)
         except Exception:
             traffic = None
+        avg_us = round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_us": round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2),
-                    "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
+                    "avg_launch_us": avg_us, "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
+        lb = getattr(conv_flops_per_image, "layer_bytes", None)
+        if lb is not None and not is_vit and not is_cnx:
+            # The same launches against the HBM roof: algorithmic bytes = each layer's input + output activations once
+            # (bf16) + its filters (bf16 shadow read by fwd/dgrad; fp32 gradient written by wgrad).  ResNet's convolutions
+            # have 64-512 channels, so most launches move more time's worth of bytes than of flops: report whichever roof
+            # the class sits closer to, and keep the other fraction beside it.
+            if dom == "conv_dgrad":
+                lb = lb[1:]
+            act = sum(i + o for i, o, _ in lb) * B
+            wts = sum(w for _, _, w in lb) * (4 if dom == "conv_wgrad" else 2)
+            gbs = (act + wts) / (kern[dom]["ms_per_step"] * 1e-3) / 1e9
+            roofline["mfma_frac"] = roofline["frac"]
+            roofline["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
+            roofline["algorithmic_mbytes_per_launch"] = round((act + wts) / kern[dom]["calls_per_step"] / 1e6, 3)
+            if gbs / PEAK_HBM_GBS > roofline["frac"]:
+                roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": roofline["hbm_frac"]})
         for k in mfma_classes:
             kern[k]["tflops"] = round(algo[k] / (kern[k]["ms_per_step"] * 1e-3) / 1e12, 2)
         for k in kern:

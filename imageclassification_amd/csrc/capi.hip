@@ -40,6 +40,9 @@ int icamd_grad_norm_launch(const float* g, long long n, float inv_scale, float m
 int icamd_adamw_ema_launch(float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n, float lr,
                            float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
                            const float* clip, const int* finite_flag, int zero_grad, hipStream_t s);
+int icamd_optim_ema_launch(int kind, float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n,
+                           float lr, float wd, float beta1, float beta2, float eps, int step, float gscale,
+                           float ema_decay, const float* clip, const int* finite_flag, int zero_grad, hipStream_t s);
 int icamd_lerp_launch(float* dst, const float* src, long long n, float w, const int* finite_flag, hipStream_t s);
 int icamd_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, hipStream_t s);
 int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
@@ -647,6 +650,16 @@ int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sh
   if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_adamw_ema_launch(p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
                                 clip, finite_flag, zero_grad, (hipStream_t)stream);
+}
+
+int icamd_optim_ema(int kind, float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr,
+                    float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
+                    const float* clip, const int32_t* finite_flag, int zero_grad, void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
+  if (p == nullptr || g == nullptr || m == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
+  if ((kind == ICAMD_OPT_ADAMW || kind == ICAMD_OPT_ADAM) && v == nullptr) return ICAMD_ERR_BAD_ARG;
+  return icamd_optim_ema_launch(kind, p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale,
+                                ema_decay, clip, finite_flag, zero_grad, (hipStream_t)stream);
 }
 
 int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream) {

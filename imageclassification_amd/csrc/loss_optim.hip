@@ -370,6 +370,85 @@ int icamd_adamw_ema_launch(float* p, float* g, float* m, float* v, float* ema, b
   return icamd_launch_status();
 }
 
+// The reference's other optimizers with trivial fused forms (optim_factory.py:66-77): torch.optim.SGD (momentum 0.9,
+// Nesterov or not, coupled weight decay), torch.optim.Adam (coupled weight decay) and timm Lion (decoupled decay, sign
+// update).  Same fusion as adamw_ema_kernel: gradient scale / clip, NaN-skip flag, EMA lerp, bf16 shadow, zero_grad.
+// KIND: 1 = Adam, 2 = SGD with momentum, 3 = SGD with Nesterov momentum, 4 = Lion.
+template <int KIND>
+__global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ ema,
+                                                        bf16_t* __restrict__ shadow, long long n4, AdamArgs a,
+                                                        const float* __restrict__ clip, const int* __restrict__ finite_flag,
+                                                        int zero_grad) {
+  if (finite_flag != nullptr && *finite_flag == 0) return;
+  const float gs = a.gscale * (clip != nullptr ? clip[1] : 1.f);
+  const float step_size = a.lr / a.bc1;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = ((f32x4*)p)[i];
+    const f32x4 gv = ((const f32x4*)g)[i];
+    f32x4 mv = ((f32x4*)m)[i];
+    f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+    if (KIND == 1) vv = ((f32x4*)v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = gv[e] * gs;
+      if (KIND == 1) {          // torch.optim.Adam: L2 term joins the gradient
+        gg += a.wd * pv[e];
+        const float mm = mv[e] + (gg - mv[e]) * (1.f - a.beta1);
+        const float v2 = vv[e] * a.beta2 + (1.f - a.beta2) * gg * gg;
+        pv[e] -= step_size * (mm / (sqrtf(v2) / a.bc2_sqrt + a.eps));
+        mv[e] = mm; vv[e] = v2;
+      } else if (KIND == 2 || KIND == 3) {   // torch.optim.SGD, dampening 0; a zero buffer reproduces buf = g at step 1
+        gg += a.wd * pv[e];
+        const float buf = a.beta1 * mv[e] + gg;
+        pv[e] -= a.lr * (KIND == 3 ? gg + a.beta1 * buf : buf);
+        mv[e] = buf;
+      } else {                  // Lion: p *= 1 - lr wd; p -= lr sign(b1 m + (1-b1) g); m = b2 m + (1-b2) g
+        const float u = mv[e] * a.beta1 + gg * (1.f - a.beta1);
+        const float sg = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+        pv[e] = pv[e] * (1.f - a.lr * a.wd) - a.lr * sg;
+        mv[e] = mv[e] + (gg - mv[e]) * (1.f - a.beta2);
+      }
+    }
+    ((f32x4*)p)[i] = pv;
+    ((f32x4*)m)[i] = mv;
+    if (KIND == 1) ((f32x4*)v)[i] = vv;
+    if (zero_grad) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ema != nullptr) {
+      f32x4 ev = ((f32x4*)ema)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ev[e] = ev[e] + a.ema_w * (pv[e] - ev[e]);
+      ((f32x4*)ema)[i] = ev;
+    }
+    if (shadow != nullptr) {
+      u32x2 sv;
+      sv[0] = pack_bf16x2(pv[0], pv[1]);
+      sv[1] = pack_bf16x2(pv[2], pv[3]);
+      ((u32x2*)shadow)[i] = sv;
+    }
+  }
+}
+
+int icamd_optim_ema_launch(int kind, float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n,
+                           float lr, float wd, float beta1, float beta2, float eps, int step, float gscale,
+                           float ema_decay, const float* clip, const int* finite_flag, int zero_grad, hipStream_t s) {
+  if (kind == 0) return icamd_adamw_ema_launch(p, g, m, v, ema, shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
+                                               clip, finite_flag, zero_grad, s);
+  if (n % 4 != 0 || step < 1 || kind < 0 || kind > 4 || (kind == 1 && v == nullptr)) return ICAMD_ERR_BAD_ARG;
+  AdamArgs a;
+  a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.gscale = gscale;
+  a.bc1 = kind == 1 ? (float)(1.0 - pow((double)beta1, (double)step)) : 1.f;
+  a.bc2_sqrt = kind == 1 ? (float)sqrt(1.0 - pow((double)beta2, (double)step)) : 1.f;
+  a.ema_w = 1.f - ema_decay;
+  const dim3 grid(grid_for(n / 4, 256)), block(256);
+  if (kind == 1) hipLaunchKernelGGL(optim_ema_kernel<1>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
+  else if (kind == 2) hipLaunchKernelGGL(optim_ema_kernel<2>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
+  else if (kind == 3) hipLaunchKernelGGL(optim_ema_kernel<3>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
+  else hipLaunchKernelGGL(optim_ema_kernel<4>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
+  return icamd_launch_status();
+}
+
 int icamd_lerp_launch(float* dst, const float* src, long long n, float w, const int* finite_flag, hipStream_t s) {
   hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dst, src, n, w, finite_flag);
   return icamd_launch_status();

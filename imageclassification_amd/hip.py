@@ -89,6 +89,8 @@ _SIGNATURES = {
     "icamd_grad_norm": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P]),
     "icamd_adamw_ema": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int,
                                 c_float, c_float, _P, _P, c_int, _P]),
+    "icamd_optim_ema": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float,
+                                c_int, c_float, c_float, _P, _P, c_int, _P]),
     "icamd_lerp": (c_int, [_P, _P, c_longlong, c_float, _P, _P]),
     "icamd_f32_to_bf16": (c_int, [_P, _P, c_longlong, _P]),
     "icamd_colsum": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),

@@ -83,10 +83,88 @@ class FusedAdamW:
             g.update(src)
 
 
+OPT_ADAMW, OPT_ADAM, OPT_SGD_MOMENTUM, OPT_SGD_NESTEROV, OPT_LION = range(5)   # include/icamd.h ICAMD_OPT_*
+
+
+class FusedOptimizer(FusedAdamW):
+    """The reference's other optimizers that have a one-pass fused form (optim_factory.py:66-77), on the same flat
+    arenas and with the same EMA / shadow / skip fusion as FusedAdamW (icamd_optim_ema):
+
+      sgd | nesterov -> torch.optim.SGD(momentum=0.9, nesterov=True)      momentum -> nesterov=False
+      adam           -> torch.optim.Adam (weight decay joins the gradient)
+      lion           -> timm Lion(betas=(0.9, 0.999)); the reference does not forward `lr` to it (optim_factory.py:77),
+                        which is invisible in training because engine.py:33-38 rewrites lr every step.
+    """
+
+    def __init__(self, model, kind, lr=1e-3, weight_decay=0.0, momentum=0.9, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(model, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+        self.kind = kind
+        g = self.param_groups[0]
+        if kind in (OPT_SGD_MOMENTUM, OPT_SGD_NESTEROV):
+            g.pop("betas"); g.pop("eps")
+            g.update(momentum=momentum, nesterov=kind == OPT_SGD_NESTEROV, dampening=0)
+        if kind == OPT_LION:
+            g.pop("eps")
+        if kind not in (OPT_ADAMW, OPT_ADAM):
+            self.exp_avg_sq = None   # only the Adam family keeps second moments
+
+    def step(self, model_ema=None, grad_scale=1.0, use_clip=False, finite_flag=None, zero_grad=False):
+        g = self.param_groups[0]
+        m = self.model
+        self.step_count += 1
+        if self.kind in (OPT_SGD_MOMENTUM, OPT_SGD_NESTEROV):
+            b1, b2, eps = g["momentum"], 0.0, 0.0
+        else:
+            b1, b2, eps = g["betas"][0], g["betas"][1], g.get("eps", 0.0)
+        ema_ptr, decay = None, 0.0
+        if model_ema is not None:
+            ema_ptr, decay = model_ema.param_arena.data_ptr(), model_ema.decay
+        hip.check(self.lib.icamd_optim_ema(self.kind, m.param_arena.data_ptr(), m.grad_arena.data_ptr(),
+                                           self.exp_avg.data_ptr(),
+                                           None if self.exp_avg_sq is None else self.exp_avg_sq.data_ptr(), ema_ptr,
+                                           m.shadow.data_ptr(), m.n_params, float(g["lr"]), float(g["weight_decay"]),
+                                           float(b1), float(b2), float(eps), self.step_count, float(grad_scale),
+                                           float(decay), self.norm_clip.data_ptr() if use_clip else None,
+                                           None if finite_flag is None else finite_flag.data_ptr(), int(zero_grad),
+                                           hip.stream_ptr()), "optim_ema")
+        m.refresh_transposed()
+        if model_ema is not None:
+            model_ema.after_fused_update(m, finite_flag)
+
+    def state_dict(self):
+        sd = super().state_dict() if self.exp_avg_sq is not None else {
+            "state": {"step": self.step_count, "exp_avg": self.exp_avg.cpu()},
+            "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        sd["kind"] = self.kind
+        return sd
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        self.step_count = int(st["step"])
+        self.exp_avg.copy_(st["exp_avg"])
+        if self.exp_avg_sq is not None:
+            self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g.update(src)
+
+
+_FUSED_KINDS = {"adamw": OPT_ADAMW, "adam": OPT_ADAM, "sgd": OPT_SGD_NESTEROV, "nesterov": OPT_SGD_NESTEROV,
+                "momentum": OPT_SGD_MOMENTUM, "lion": OPT_LION}
+
+
 def create_optimizer(opt, lr, weight_decay, model, filter_bias_and_bn=True):
-    """`adamw` (the default recipe, reference train.py:50, optim_factory.py:74-75) is the fused path.
-    The other 19 optimizer names of the reference need timm/apex classes and are outside this hot path."""
-    name = opt.lower().split("_")[-1]
-    if name != "adamw":
-        raise ValueError(f"optimizer '{opt}' is not part of the MI355X hot path (only adamw is fused); see DESIGN.md")
-    return FusedAdamW(model, lr=lr, weight_decay=weight_decay)
+    """Name handling of reference optim_factory.py:50-122: lower-case, the last `_`-separated token selects the optimizer.
+    `adamw` (the default recipe, train.py:50) is the fused hot path; sgd/nesterov, momentum, adam and lion are the other
+    one-pass forms.  The remaining names need timm/apex classes (nadam, radam, adamp, sgdp, adadelta,
+    adafactor, adahessian, rmsprop(tf), novograd, fused*, lookahead_*) and are not part of this build."""
+    parts = opt.lower().split("_")
+    name = parts[-1]
+    if name not in _FUSED_KINDS or (len(parts) > 1 and parts[0] == "lookahead"):
+        raise ValueError(f"optimizer '{opt}' is not built for the MI355X path (available: {sorted(_FUSED_KINDS)}); "
+                         "see DESIGN.md")
+    kind = _FUSED_KINDS[name]
+    if kind == OPT_ADAMW:
+        return FusedAdamW(model, lr=lr, weight_decay=weight_decay)
+    if kind == OPT_LION:
+        return FusedOptimizer(model, kind, lr=1e-4, weight_decay=weight_decay, betas=(0.9, 0.999))
+    return FusedOptimizer(model, kind, lr=lr, weight_decay=weight_decay)

@@ -166,6 +166,43 @@ class NativeScalerWithGradNormCount:
 # ---------------------------------------------------------------------------------------------------
 # distributed glue (reference utils.py:311-375): one process per GPU, RCCL over xGMI via torch.distributed
 # ---------------------------------------------------------------------------------------------------
+class RASampler(torch.utils.data.Sampler):
+    """Repeated-augmentation sampler with the reference's exact index stream (/root/reference/utils.py:17-63; pinned by
+    tests/golden/ra_sampler.json): the epoch-seeded permutation with every index tripled, wrapped to a multiple of the
+    world size, dealt round-robin to the ranks, and cut to floor(len//256*256 / world) draws per rank."""
+
+    REPEATS = 3
+
+    def __init__(self, dataset, num_replicas=None, rank=None, shuffle=True):
+        if num_replicas is None:
+            num_replicas = get_world_size()
+        if rank is None:
+            rank = get_rank()
+        self.n = len(dataset)
+        self.num_replicas, self.rank, self.shuffle, self.epoch = num_replicas, rank, shuffle, 0
+        self.num_samples = -(-self.n * self.REPEATS // num_replicas)        # ceil(3n / world)
+        self.total_size = self.num_samples * num_replicas
+        self.num_selected_samples = (self.n // 256 * 256) // num_replicas
+
+    def __iter__(self):
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.epoch))
+        else:
+            order = torch.arange(self.n)
+        stream = order.repeat_interleave(self.REPEATS)
+        pad = self.total_size - stream.numel()
+        if pad > 0:
+            stream = torch.cat([stream, stream[:pad]])
+        mine = stream[self.rank:self.total_size:self.num_replicas]
+        return iter(mine[:self.num_selected_samples].tolist())
+
+    def __len__(self):
+        return self.num_selected_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
 def is_dist_avail_and_initialized():
     return dist.is_available() and dist.is_initialized()
 

@@ -206,6 +206,15 @@ int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm
 int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
                     float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
                     const int32_t* finite_flag, int zero_grad, void* stream);
+/* The reference's other optimizers with a one-pass fused form (optim_factory.py:66-77), same fusion contract as
+ * icamd_adamw_ema.  kind: ICAMD_OPT_ADAMW (identical to icamd_adamw_ema), ICAMD_OPT_ADAM (torch.optim.Adam, wd joins
+ * the gradient), ICAMD_OPT_SGD_MOMENTUM / ICAMD_OPT_SGD_NESTEROV (torch.optim.SGD, momentum = beta1, dampening 0, wd
+ * joins the gradient; m is the momentum buffer, zero-initialised), ICAMD_OPT_LION (timm Lion: p *= 1 - lr*wd;
+ * p -= lr*sign(beta1*m + (1-beta1)*g); m = beta2*m + (1-beta2)*g).  v is only used by the Adam kinds (else may be NULL). */
+enum { ICAMD_OPT_ADAMW = 0, ICAMD_OPT_ADAM = 1, ICAMD_OPT_SGD_MOMENTUM = 2, ICAMD_OPT_SGD_NESTEROV = 3, ICAMD_OPT_LION = 4 };
+int icamd_optim_ema(int kind, float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr,
+                    float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
+                    const float* clip, const int32_t* finite_flag, int zero_grad, void* stream);
 int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream);
 int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream);

@@ -193,6 +193,62 @@ def adamw_ema_steps(p0, grads, lrs, wds, betas=(0.9, 0.999), eps=1e-8, ema0=None
     return p.detach(), st["exp_avg"], st["exp_avg_sq"], ema
 
 
+class LionRef(torch.optim.Optimizer):
+    """timm.optim.Lion restated (timm is absent here; algorithm of Chen et al. 2023 as timm implements it and as the
+    reference constructs it, /root/reference/optim_factory.py:76-77: betas=(0.9, 0.999), decoupled weight decay):
+        p *= 1 - lr*wd ; p -= lr * sign(beta1*m + (1-beta1)*g) ; m = beta2*m + (1-beta2)*g.     Parity unpinned."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p)
+                m = st["exp_avg"]
+                p.mul_(1.0 - group["lr"] * group["weight_decay"])
+                p.add_(torch.sign(m * b1 + p.grad * (1.0 - b1)), alpha=-group["lr"])
+                m.lerp_(p.grad, 1.0 - b2)
+
+
+def optimizer_ema_steps(name, p0, grads, lrs, wds, ema0=None, ema_decay=0.9995, gscale=1.0):
+    """The reference's non-default optimizers (optim_factory.py:66-77) for len(grads) steps with the per-step lr / wd
+    injection of engine.py:33-38 and the ModelEmaV3 lerp: name in sgd|nesterov|momentum|adam|lion.
+    Returns (p, first-moment / momentum buffer, second moment or None, ema)."""
+    p = torch.nn.Parameter(p0.clone().float())
+    groups = [{"params": [p], "weight_decay": wds[0]}]
+    if name in ("sgd", "nesterov"):
+        opt = torch.optim.SGD(groups, lr=lrs[0], momentum=0.9, nesterov=True, weight_decay=0.0)
+    elif name == "momentum":
+        opt = torch.optim.SGD(groups, lr=lrs[0], momentum=0.9, nesterov=False, weight_decay=0.0)
+    elif name == "adam":
+        opt = torch.optim.Adam(groups, lr=lrs[0], weight_decay=0.0)
+    elif name == "lion":
+        opt = LionRef(groups, betas=(0.9, 0.999))
+    else:
+        raise ValueError(name)
+    ema = None if ema0 is None else ema0.clone().float()
+    for g, lr, wd in zip(grads, lrs, wds):
+        for group in opt.param_groups:
+            group["lr"] = lr
+            if group["weight_decay"] > 0:
+                group["weight_decay"] = wd
+        p.grad = (g.float() * gscale).clone()
+        opt.step()
+        opt.zero_grad()
+        if ema is not None:
+            ema.lerp_(p.detach(), 1.0 - ema_decay)
+    st = opt.state[p]
+    m = st.get("momentum_buffer", st.get("exp_avg"))
+    return p.detach(), m, st.get("exp_avg_sq"), ema
+
+
 def grad_norm(g, max_norm=0.0):
     norm = torch.linalg.vector_norm(g.double()).float()
     coef = 1.0

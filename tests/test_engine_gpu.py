@@ -153,3 +153,32 @@ def test_grad_clip_and_ema_in_engine():
     moved = (net.param_arena - p0).abs().max().item()
     assert 0 < moved <= 1.01e-3                          # first Adam step moves every weight by at most lr
     assert torch.allclose(ema.param_arena, p0 + 0.5 * (net.param_arena - p0), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["sgd", "lion"])
+def test_train_one_epoch_with_the_other_fused_optimizers(name):
+    """The reference's `--opt sgd|lion` recipes through the same boundary (optim_factory.py:66-77): losses track the
+    oracle loop and the classifier's update has the oracle's direction and size."""
+    from imageclassification_amd.optim_factory import create_optimizer
+    C, B, steps = 10, 8, 3
+    ref, net, _, _ = _setup(C)
+    opt = create_optimizer(name, 1e-4, 5e-4, net)
+    groups = [{"params": list(ref.parameters()), "weight_decay": 5e-4}]
+    opt_ref = (torch.optim.SGD(groups, lr=1e-4, momentum=0.9, nesterov=True, weight_decay=0.0) if name == "sgd"
+               else R.LionRef(groups, betas=(0.9, 0.999)))
+    data = _loader(steps, B, C, seed=23)
+    fc0 = ref.state_dict()["fc.weight"].clone()
+    lrs = [1e-4, 2e-4, 3e-4] if name == "sgd" else [1e-6] * steps
+    rstats = E.train_one_epoch_ref(ref, E.LabelSmoothingCrossEntropyRef(0.1), [(x.clone(), y.clone()) for x, y in data],
+                                   opt_ref, lr_schedule_values=lrs, wd_schedule_values=[5e-4] * steps,
+                                   num_training_steps_per_epoch=steps, num_classes=C)
+    stats = _train(net, opt, data, C, lr=lrs, wd=[5e-4] * steps)
+    assert abs(stats["loss"] - rstats["loss"]) <= 5e-3 * rstats["loss"]
+    assert opt.step_count == steps and opt.exp_avg_sq is None
+    d_ref = ref.state_dict()["fc.weight"] - fc0
+    d_hip = net.state_dict()["fc.weight"].cpu().float() - fc0
+    if name == "sgd":
+        assert R.rel_l2(d_hip, d_ref) <= 5e-2
+    else:   # sign updates: every weight moves by lr per step; the sign pattern agrees except where |update| ~ 0
+        agree = (torch.sign(d_hip) == torch.sign(d_ref)).float().mean()
+        assert agree >= 0.97

@@ -222,3 +222,42 @@ def test_imagefolder_split_and_eval_transform(tmp_path):
     assert xt.shape == (3, 16, 16) and torch.isfinite(xt).all()
     with pytest.raises(NotImplementedError):
         D.TrainTransform(16, auto_augment="rand-m9-mstd0.5-inc1")
+
+
+def test_ra_sampler_matches_reference_index_streams():
+    """RASampler against index lists produced by the reference's own class (tests/golden/make_sampler_fixture.py)."""
+    from imageclassification_amd.utils import RASampler
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ra_sampler.json")))
+    assert len(fx["cases"]) >= 10
+    for c in fx["cases"]:
+        s = RASampler(list(range(c["n"])), num_replicas=c["replicas"], rank=c["rank"], shuffle=c["shuffle"])
+        s.set_epoch(c["epoch"])
+        assert len(s) == c["len"]
+        assert list(iter(s)) == c["indices"], (c["n"], c["replicas"], c["rank"], c["epoch"])
+
+
+def test_create_optimizer_names_follow_the_reference_factory():
+    """Name parsing of reference optim_factory.py:50-122 for the fused kinds; everything else is refused loudly."""
+    from imageclassification_amd import optim_factory as OF
+
+    class FakeModel:
+        n_params = 64
+        param_arena = torch.zeros(64)
+
+        def parameters(self):
+            return [self.param_arena]
+
+    m = FakeModel()
+    for name, kind in [("adamw", OF.OPT_ADAMW), ("AdamW", OF.OPT_ADAMW), ("sgd", OF.OPT_SGD_NESTEROV),
+                       ("nesterov", OF.OPT_SGD_NESTEROV), ("momentum", OF.OPT_SGD_MOMENTUM), ("adam", OF.OPT_ADAM),
+                       ("lion", OF.OPT_LION)]:
+        opt = OF.create_optimizer(name, 1e-3, 0.05, m)
+        assert getattr(opt, "kind", OF.OPT_ADAMW) == kind
+        g = opt.param_groups[0]
+        assert g["weight_decay"] == 0.05 and g["name"] == "decay"
+        if kind in (OF.OPT_SGD_MOMENTUM, OF.OPT_SGD_NESTEROV):
+            assert g["momentum"] == 0.9 and g["nesterov"] == (kind == OF.OPT_SGD_NESTEROV)
+            assert opt.exp_avg_sq is None
+    for bad in ("radam", "lookahead_adamw", "fusedlamb", "rmsprop"):
+        with pytest.raises(ValueError):
+            OF.create_optimizer(bad, 1e-3, 0.05, m)

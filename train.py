@@ -100,8 +100,11 @@ def main(args):
         dataset_train, dataset_val, num_classes = build_dataset(args=args)
 
     num_tasks, global_rank = utils.get_world_size(), utils.get_rank()
-    sampler_train = torch.utils.data.DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank,
-                                                        shuffle=True, seed=args.seed)
+    if args.RASampler:   # reference train.py:125-128
+        sampler_train = utils.RASampler(dataset_train, num_replicas=num_tasks, rank=global_rank, shuffle=True)
+    else:
+        sampler_train = torch.utils.data.DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank,
+                                                            shuffle=True, seed=args.seed)
     sampler_val = torch.utils.data.SequentialSampler(dataset_val)
     data_loader_train = torch.utils.data.DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size,
                                                     num_workers=args.num_workers, pin_memory=True, drop_last=True)
