@@ -44,6 +44,8 @@ int icamd_optim_ema_launch(int kind, float* p, float* g, float* m, float* v, flo
                            float lr, float wd, float beta1, float beta2, float eps, int step, float gscale,
                            float ema_decay, const float* clip, const int* finite_flag, int zero_grad, hipStream_t s);
 int icamd_lerp_launch(float* dst, const float* src, long long n, float w, const int* finite_flag, hipStream_t s);
+int icamd_bn_fold_launch(const float* w, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                         int Cout, int K, bf16_t* w_folded, float* shift, hipStream_t s);
 int icamd_f32_to_bf16_launch(const float* src, bf16_t* dst, long long n, hipStream_t s);
 int icamd_filter_transpose_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
                                   int njobs, hipStream_t s);
@@ -150,9 +152,8 @@ int icamd_conv2d_stats_rows(const icamd_conv_desc* d) {
   return (int)((M + 127) / 128);
 }
 
-int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
-                     const void* addend, float* stats, void* stream) {
-  ProfScope _prof(PC_IGEMM_FWD, stream);
+static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                         const void* addend, float* stats, int relu, void* stream) {
   if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
   if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && stats == nullptr &&
@@ -160,13 +161,13 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.addend = (const bf16_t*)addend; g.bias = bias;
-    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
+    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin; g.relu = relu;
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
   }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w; p.out = (bf16_t*)y;
-  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats;
+  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats; p.relu = relu;
   p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin;
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
   p.P = d->OH; p.Q = d->OW; p.M = d->N * d->OH * d->OW;
@@ -180,6 +181,29 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
         p.dh[t] = (short)(r - d->pad); p.dw[t] = (short)(s - d->pad); p.wtap[t] = (short)t;
       }
   return icamd_igemm_launch(p, (hipStream_t)stream);
+}
+
+int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                     const void* addend, float* stats, void* stream) {
+  ProfScope _prof(PC_IGEMM_FWD, stream);
+  return conv_fwd_impl(d, x, w, y, bias, addend, stats, 0, stream);
+}
+
+int icamd_conv2d_fwd_act(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                         const void* addend, int relu, void* stream) {
+  ProfScope _prof(PC_IGEMM_FWD, stream);
+  return conv_fwd_impl(d, x, w, y, bias, addend, nullptr, relu ? 1 : 0, stream);
+}
+
+int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, int Cout, int K, void* w_folded, float* shift,
+                          void* stream) {
+  ProfScope _prof(PC_BN_FINALIZE, stream);
+  if (w == nullptr || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr ||
+      w_folded == nullptr || shift == nullptr || Cout <= 0 || K <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_bn_fold_launch(w, gamma, beta, running_mean, running_var, eps, Cout, K, (bf16_t*)w_folded, shift,
+                              (hipStream_t)stream);
 }
 
 static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,

@@ -28,7 +28,7 @@ constexpr int BK = 64;
 #define ICAMD_IGEMM_STAGES 1   // 1: single LDS stage, overlap comes from 4 workgroups per CU; 2: double buffer, 2 per CU
 #endif
 
-// EPI 0: out = acc (+bias)(+addend); optional statistics of the rounded outputs (BatchNorm forward).
+// EPI 0: out = [relu](acc (+bias)(+addend)); optional statistics of the rounded outputs (BatchNorm forward).
 // EPI 1: data-gradient with the next BatchNorm-backward fused in: g = (acc + addend) * [ReLU mask], out = g, and the
 //        partial rows hold sum(g) and sum(g * xhat), xhat from the BN input `bnb_y` (BatchNorm backward, pass 1).
 template <int BN, bool CIN8, int EPI>
@@ -284,6 +284,10 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
           v[1] += (ab[i] & 2u) ? bf16_hi(a[0]) : 0.f;
           v[2] += (ab[i] & 4u) ? bf16_lo(a[1]) : 0.f;
           v[3] += (ab[i] & 8u) ? bf16_hi(a[1]) : 0.f;
+        }
+        if (p.relu) {   // inference epilogue (BatchNorm folded into filters + bias): NaN passes through like torch.relu
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
         }
         const int ml = wm * 64 + i * 16 + fr;
         u32x2 pk;

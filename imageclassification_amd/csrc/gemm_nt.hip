@@ -1,6 +1,6 @@
 // Large-tile dense GEMM for gfx950 used by the pointwise (1x1, stride 1) convolution forward / data-gradient when the
 // problem is big enough to be MFMA-bound (ViT's Linear layers, ResNet's deep 1x1 layers):
-//   out[m][n] = sum_k A[m][k] * B[n][k]  (+ bias[n]) (+ addend[m][n]),  A = activations [M][K], B = filters [N][K], bf16.
+//   out[m][n] = [relu](sum_k A[m][k] * B[n][k]  (+ bias[n]) (+ addend[m][n])),  A = activations [M][K], B = filters [N][K], bf16.
 //
 // 256 x TN output tile per workgroup (TN = 128: 4 wavefronts, two workgroups per CU; TN = 256: 8 wavefronts, one per
 // CU); every wave owns 128 x 64 = 32 accumulator tiles of v_mfma_f32_16x16x32_bf16.  K is walked in 32-wide stages
@@ -181,6 +181,10 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
         const int mr = (m0 + ml < p.M) ? m0 + ml : 0;
         const u32x2 a = *(const u32x2*)(p.addend + (long long)mr * p.N + cgc);
         v[0] += bf16_lo(a[0]); v[1] += bf16_hi(a[0]); v[2] += bf16_lo(a[1]); v[3] += bf16_hi(a[1]);
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
       }
       u32x2 pk;
       pk[0] = pack_bf16x2(v[0], v[1]);

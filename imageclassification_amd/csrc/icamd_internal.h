@@ -19,6 +19,7 @@ struct IgemmParams {
   const bf16_t* bnb_mask;  // post-activation tensor for the ReLU mask, or nullptr: mask = bnb_y*scale+shift > 0
   const float *bnb_mean, *bnb_invstd, *bnb_scale, *bnb_shift;
   int bnb_relu;
+  int relu;              // EPI 0 only: clamp the sum at zero before rounding (inference epilogue)
   int N, IH, IW, Cin;
   int OH, OW, Cout;
   int P, Q, M;           // output sub-grid and row count N*P*Q
@@ -41,6 +42,7 @@ struct GemmNtParams {
   const bf16_t* addend;  // optional [M][N]
   const float* bias;     // optional [N]
   int M, N, K;
+  int relu;              // clamp at zero before rounding
   int ntiles_n;          // filled by the launcher
 };
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream);

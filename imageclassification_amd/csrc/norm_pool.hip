@@ -740,3 +740,27 @@ int icamd_pack_input_launch(const float* x, bf16_t* out, int B, int Cin, int H, 
                      yl, yh, xl, xh);
   return icamd_launch_status();
 }
+
+
+// ---- inference: fold a BatchNorm into the filters of the convolution in front of it ------------------------------
+// w_folded[co][k] = bf16(w[co][k] * gamma[co] / sqrt(running_var[co] + eps)); shift[co] = beta - running_mean * scale.
+// One workgroup per output channel.
+namespace {
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rm,
+                                                      const float* __restrict__ rv, float eps, int K,
+                                                      bf16_t* __restrict__ out, float* __restrict__ shift) {
+  const int co = blockIdx.x;
+  const float scale = gamma[co] / sqrtf(rv[co] + eps);
+  if (threadIdx.x == 0) shift[co] = beta[co] - rm[co] * scale;
+  const float* src = w + (long long)co * K;
+  bf16_t* dst = out + (long long)co * K;
+  for (int k = threadIdx.x; k < K; k += 256) dst[k] = f32_to_bf16(src[k] * scale);
+}
+}  // namespace
+
+int icamd_bn_fold_launch(const float* w, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                         int Cout, int K, bf16_t* w_folded, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)Cout), dim3(256), 0, s, w, gamma, beta, rm, rv, eps, K, w_folded, shift);
+  return icamd_launch_status();
+}

@@ -28,6 +28,7 @@ class ModelEmaV3:
         self.module.buffer_arena.copy_(model.buffer_arena)
         self.module.num_batches_tracked = model.num_batches_tracked
         self.module.refresh_shadow()
+        self.module._fold_dirty = True
 
     def after_fused_update(self, model, finite_flag=None):
         """Called by FusedAdamW.step after the fused parameter lerp: BN buffers + bookkeeping."""
@@ -37,6 +38,7 @@ class ModelEmaV3:
                                       hip.stream_ptr()), "ema buffers")
         self.module.num_batches_tracked = model.num_batches_tracked
         self.module.shadow_stale = True
+        self.module._fold_dirty = True   # ResNet eval fast path re-folds BatchNorm before the next eval forward
 
     def update(self, model):
         """Stand-alone update (when the optimizer step was not the fused one)."""

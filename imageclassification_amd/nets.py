@@ -15,13 +15,12 @@ zero-padded to a multiple of 64); everything 256 B aligned inside the arenas.
 """
 import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import torch
 
 from . import hip
-
-import os
 
 BN_EPS = 1e-5
 _FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
@@ -88,6 +87,9 @@ class ResNet:
         self.num_classes = num_classes
         self.device = torch.device(device)
         self.training = True
+        self._fold_dirty = True
+        # eval forwards use BatchNorm-folded filters (ICAMD_EVAL_FOLD=0 keeps the separate BatchNorm pass)
+        self.fold_eval = os.environ.get("ICAMD_EVAL_FOLD", "1") != "0"
         block, layers = ARCHS[arch]
         self.block = block
         self.expansion = 4 if block == "bottleneck" else 1
@@ -291,6 +293,7 @@ class ResNet:
         self.param_arena.copy_(host)
         self.buffer_arena.copy_(bufs)
         self.refresh_shadow()
+        self._fold_dirty = True
         return missing
 
     def state_dict(self):
@@ -345,7 +348,72 @@ class ResNet:
 
     def train(self, mode=True):
         self.training = bool(mode)
+        self._fold_dirty = True     # parameters / running statistics may move before the next eval forward
         return self
+
+    # ------------------------------------------------------------------ inference form
+    def fold_batchnorm(self):
+        """Eval fast path: fold every BatchNorm (running statistics) into the bf16 filters of the convolution in front
+        of it, so an eval forward is one kernel per convolution (bias = BN shift, residual add and ReLU in the epilogue)
+        with no BatchNorm pass over the activations.  Re-done whenever the mode, the weights or the EMA changed."""
+        dev = self.device
+        if getattr(self, "shadow_eval", None) is None:
+            self.shadow_eval = torch.empty_like(self.shadow)
+            self.eval_shift = torch.zeros(sum(b.c for b in self.bns), dtype=torch.float32, device=dev)
+            off = 0
+            for b in self.bns:
+                b.shift_offset = off
+                off += b.c
+        s = hip.stream_ptr()
+        pairs = [(self.stem_conv, self.stem_bn)]
+        for blk in self.blocks:
+            pairs += list(zip(blk["convs"], blk["bns"]))
+            if "down_conv" in blk:
+                pairs.append((blk["down_conv"], blk["down_bn"]))
+        for conv, bn in pairs:
+            rm = self.buffer_arena.data_ptr() + 4 * bn.buf_offset
+            hip.check(self.lib.icamd_bn_fold_filters(self._pf(conv.w), self._pf(bn.weight), self._pf(bn.bias), rm,
+                                                     rm + 4 * bn.c, BN_EPS, conv.cout_p, conv.k * conv.k * conv.cin_p,
+                                                     self.shadow_eval.data_ptr() + 2 * conv.w.offset,
+                                                     self.eval_shift.data_ptr() + 4 * bn.shift_offset, s), bn.name)
+        self._fold_dirty = False
+
+    def _conv_act_eval(self, conv, bn, x, N, IH, IW, out, residual, relu, s):
+        d = conv.desc(N, IH, IW)
+        hip.check(self.lib.icamd_conv2d_fwd_act(ctypes.byref(d), x, self.shadow_eval.data_ptr() + 2 * conv.w.offset,
+                                                out.data_ptr(), self.eval_shift.data_ptr() + 4 * bn.shift_offset, residual,
+                                                int(relu), s), conv.name)
+        return d
+
+    def _forward_eval_folded(self, ws):
+        lib = self.lib
+        s = hip.stream_ptr()
+        N, H, W = ws["N"], ws["H"], ws["W"]
+        if self._fold_dirty:
+            self.fold_batchnorm()
+        d0 = self._conv_act_eval(self.stem_conv, self.stem_bn, ws["x8"].data_ptr(), N, H, W, ws["a0"], None, True, s)
+        hip.check(lib.icamd_maxpool3x3s2_fwd(ws["a0"].data_ptr(), ws["p0"].data_ptr(), None, N, d0.OH, d0.OW, 64, s),
+                  "maxpool")
+        x = ws["p0"]
+        h, w = x.shape[1], x.shape[2]
+        for blk, b in zip(self.blocks, ws["blocks"]):
+            if "down_conv" in blk:
+                self._conv_act_eval(blk["down_conv"], blk["down_bn"], x.data_ptr(), N, h, w, b["ad"], None, False, s)
+                idn = b["ad"]
+            else:
+                idn = x
+            cur, ch, cw = x, h, w
+            n = len(blk["convs"])
+            for i, (conv, bn) in enumerate(zip(blk["convs"], blk["bns"])):
+                d = self._conv_act_eval(conv, bn, cur.data_ptr(), N, ch, cw, b["a"][i],
+                                        idn.data_ptr() if i == n - 1 else None, True, s)
+                cur, ch, cw = b["a"][i], d.OH, d.OW
+            x, h, w = cur, ch, cw
+        hip.check(lib.icamd_avgpool_fwd(x.data_ptr(), ws["pooled"].data_ptr(), N, h * w, self.feat_dim, s), "avgpool")
+        dfc = self.fc.desc(N, 1, 1)
+        hip.check(lib.icamd_conv2d_fwd(ctypes.byref(dfc), ws["pooled"].data_ptr(), self._w(self.fc),
+                                       ws["logits"].data_ptr(), self._pf(self.fc.b), None, None, s), "fc")
+        return ws["logits"]
 
     def eval(self):
         return self.train(False)
@@ -488,6 +556,8 @@ class ResNet:
         lib = self.lib
         s = hip.stream_ptr()
         N, H, W = ws["N"], ws["H"], ws["W"]
+        if not self.training and self.fold_eval:
+            return self._forward_eval_folded(ws)
         if self.training:
             self.num_batches_tracked += 1
         d0 = self._conv_bn_fwd(ws, self.stem_conv, self.stem_bn, ws["x8"].data_ptr(), N, H, W, ws["y0"], ws["a0"], None,

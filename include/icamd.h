@@ -49,6 +49,15 @@ int icamd_conv2d_stats_rows(const icamd_conv_desc* d);
  * (BatchNorm batch statistics, consumed by icamd_bn_train_finalize). */
 int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                      const void* addend, float* stats, void* stream);
+/* Inference form of icamd_conv2d_fwd (evaluate(), engine.py:145-225, on a model whose BatchNorms were folded with
+ * icamd_bn_fold_filters): y = [relu](conv(x, w) + bias + addend), one rounding; no statistics. */
+int icamd_conv2d_fwd_act(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
+                         const void* addend, int relu, void* stream);
+/* Eval-mode BatchNorm (running statistics) folded into the [Cout][K] fp32 filters in front of it:
+ * w_folded = bf16(w * gamma/sqrt(running_var+eps)) per output channel, shift = beta - running_mean * that scale. */
+int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, int Cout, int K, void* w_folded, float* shift,
+                          void* stream);
 
 /* dx = conv_transpose(dy, w) (+ addend shaped like dx).  w_t is the [Cin][KH][KW][Cout] transposed bf16 filter
  * (icamd_filter_transpose).  Requires Cout % 64 == 0.  addend_maskbits (optional, 1 bit per addend element, as

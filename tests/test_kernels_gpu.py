@@ -204,6 +204,50 @@ def test_pointwise_large_tile_gemm_forced_small_k():
     assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 1, 1, 0), (3, 9, 7, 64, 128, 3, 1, 1), (2, 16, 16, 8, 64, 7, 2, 3),
+                                  (2, 14, 14, 256, 512, 1, 2, 0)])
+def test_conv_fwd_act_and_bn_fold(lib, case):
+    """Inference epilogue: y = relu(conv(x, w_folded) + shift + residual) with w_folded/shift from icamd_bn_fold_filters,
+    against eval-mode BatchNorm applied to the fp32 convolution of the same bf16 inputs (oracle)."""
+    hip = _hip()
+    N, H, W, Cin, Cout, k, st, pad = case
+    d = hip.conv_desc(N, H, W, Cin, Cout, k, k, st, pad)
+    g = torch.Generator().manual_seed(31)
+    x = rnd_bf16(N, H, W, Cin, seed=32)
+    w = torch.randn(Cout, k, k, Cin, generator=g) * (1.0 / (k * k * Cin)) ** 0.5
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    rm, rv = torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.5
+    res = rnd_bf16(N, d.OH, d.OW, Cout, seed=33)
+    wd_, gd, bd, rmd, rvd = w.to(DEV), gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    wf = torch.empty(Cout, k, k, Cin, dtype=torch.bfloat16, device=DEV)
+    shift = torch.empty(Cout, device=DEV)
+    assert lib.icamd_bn_fold_filters(hip.ptr(wd_), hip.ptr(gd), hip.ptr(bd), hip.ptr(rmd), hip.ptr(rvd), 1e-5, Cout,
+                                     k * k * Cin, hip.ptr(wf), hip.ptr(shift), hip.stream_ptr()) == 0
+    sync()
+    scale = gamma / torch.sqrt(rv + 1e-5)
+    assert torch.equal(wf.float().cpu(), R.bf16_round(w * scale.view(-1, 1, 1, 1)))
+    assert torch.allclose(shift.cpu(), beta - rm * scale, rtol=1e-6, atol=1e-7)
+    xd, rd = to_dev_bf16(x), to_dev_bf16(res)
+    for use_res, relu in ((False, True), (True, True), (True, False)):
+        y = torch.full((N, d.OH, d.OW, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib.icamd_conv2d_fwd_act(ctypes.byref(d), hip.ptr(xd), hip.ptr(wf), hip.ptr(y), hip.ptr(shift),
+                                        hip.ptr(rd) if use_res else None, int(relu), hip.stream_ptr()) == 0
+        sync()
+        # same folded bf16 filters on the CPU: exact restatement of what the kernel computes
+        ref = R.conv2d_fwd(x, wf.float().cpu(), st, pad, shift.cpu(), res if use_res else None)
+        if relu:
+            ref = ref.clamp_min(0)
+        got = y.float().cpu()
+        assert R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
+        # and the unfolded definition: BN(conv(x, bf16(w))) within bf16 weight-rounding noise
+        full = R.nchw_to_nhwc(torch.nn.functional.batch_norm(
+            R.nhwc_to_nchw(R.conv2d_fwd(x, R.bf16_round(w), st, pad)), rm, rv, gamma, beta, False, 0.0, 1e-5))
+        full = full + (res if use_res else 0)
+        if relu:
+            full = full.clamp_min(0)
+        assert R.rel_l2(got, full) <= 1e-2
+
+
 WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0)]
 
 

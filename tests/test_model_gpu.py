@@ -170,8 +170,67 @@ def test_eval_mode_and_call_interface():
         out = ref(x)
     got = net(x.cuda()).float().cpu()
     assert got.shape == (6, C)
-    assert R.rel_l2(got, out) <= 5e-3
+    # The default eval forward is the BatchNorm-folded one (different bf16 rounding points from the training path the
+    # bf16_points oracle mirrors): both are priced against the oracle WITHOUT rounding points, i.e. the reference's fp32
+    # arithmetic, and the unfolded path additionally against its own mirror.
+    exact = ResNetRef("resnet18", C, bf16_points=False, zero_init_last=False)
+    exact.load_state_dict(ref.state_dict())
+    exact.eval()
+    with torch.no_grad():
+        truth = exact(x)
+    net.fold_eval = False
+    plain = net(x.cuda()).float().cpu()
+    net.fold_eval = True
+    assert R.rel_l2(plain, out) <= 5e-3
+    e_fold, e_plain = R.rel_l2(got, truth), R.rel_l2(plain, truth)
+    print(f"eval logits vs fp32 reference: folded {e_fold:.2e}, separate BatchNorm pass {e_plain:.2e}")
+    assert e_fold <= 1e-2 and e_fold <= 1.5 * e_plain
     assert net.num_batches_tracked == 0
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_eval_fast_path_folds_batchnorm(arch):
+    """eval forward with BatchNorm folded into the filters (one kernel per convolution) against the oracle's
+    eval forward and against the unfolded HIP eval path, with non-trivial running statistics and affine terms; the fold is
+    redone after the weights change."""
+    C = 10
+    ref, net = _pair(arch, C, seed=4)
+    g = torch.Generator().manual_seed(10)
+    sd = ref.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.2
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith("bn1.weight") or k.endswith("bn2.weight") or k.endswith("bn3.weight") or k.endswith("downsample.1.weight"):
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif "bn" in k and k.endswith(".bias"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+    ref.load_state_dict(sd)
+    net.load_state_dict(sd)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    exact = ResNetRef(arch, C, bf16_points=False, zero_init_last=False)   # the reference's fp32 arithmetic
+    exact.load_state_dict(sd)
+    exact.eval()
+    net.eval()
+    with torch.no_grad():
+        want = exact(x)
+    assert net.fold_eval
+    folded = net(x.cuda()).float().cpu()
+    net.fold_eval = False
+    unfolded = net(x.cuda()).float().cpu()
+    net.fold_eval = True
+    e_fold, e_plain = R.rel_l2(folded, want), R.rel_l2(unfolded, want)
+    print(f"{arch} eval logits vs fp32 reference: folded {e_fold:.2e}, separate BatchNorm pass {e_plain:.2e}")
+    assert e_fold <= 1.5e-2 and e_fold <= 1.5 * e_plain
+    # a weight change invalidates the fold
+    sd2 = {k: (v * 1.25 if k == "conv1.weight" else v) for k, v in sd.items()}
+    exact.load_state_dict(sd2)
+    net.load_state_dict(sd2)
+    with torch.no_grad():
+        want2 = exact(x)
+    got2 = net(x.cuda()).float().cpu()
+    assert R.rel_l2(got2, want2) <= 1.5e-2 and R.rel_l2(got2, folded) > R.rel_l2(got2, want2)
 
 
 def test_three_optimizer_steps_track_oracle():
