@@ -250,7 +250,8 @@ void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split) {
   const int bmk = wgrad_tile(Ktot), bnc = wgrad_tile(Cout);
   const int tiles = ((Ktot + bmk - 1) / bmk) * ((Cout + bnc - 1) / bnc);
   int s = (M + rows_target - 1) / rows_target;
-  const int smin = (512 + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
+  static const int blocks_min = []() { const char* e = getenv("ICAMD_WGRAD_BLOCKS_MIN"); return e ? atoi(e) : 512; }();
+  const int smin = (blocks_min + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
   if (s < smin) s = smin;
   if (s > smax) s = smax;
   const int scap = (M + BKR - 1) / BKR;

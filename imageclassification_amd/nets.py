@@ -24,6 +24,7 @@ from . import hip
 
 BN_EPS = 1e-5
 _FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
+_WGRAD_STREAM = os.environ.get("ICAMD_WGRAD_STREAM", "1") != "0"
 BN_MOMENTUM = 0.1
 
 ARCHS = {
@@ -497,10 +498,11 @@ class ResNet:
         return ws
 
     def _grad_buffers(self, ws):
-        """Seven activation-sized scratch buffers shared by the whole backward pass (allocated on first use)."""
+        """Activation-sized scratch buffers shared by the whole backward pass (allocated on first use): D0, D1, T, DA and a
+        pool of four conv-output-gradient buffers (the fused variant uses the first seven as before)."""
         if "gbuf" not in ws:
             n = ws["max_act"]
-            ws["gbuf"] = [torch.empty(n, dtype=torch.bfloat16, device=self.device) for _ in range(7)]
+            ws["gbuf"] = [torch.empty(n, dtype=torch.bfloat16, device=self.device) for _ in range(8)]
         return ws["gbuf"]
 
     # ------------------------------------------------------------------ primitive wrappers
@@ -599,22 +601,58 @@ class ResNet:
     # ------------------------------------------------------------------ backward
     def backward_packed(self, ws, accumulate=False):
         """Backward from ws['dlogits'] (bf16 [N, ncls_p]); fills the flat fp32 gradient arena.
-        Gradients become final in reverse layer order; `grad_ready_hook(lo, hi)` is called as ranges complete."""
+        Gradients become final in reverse layer order; `grad_ready_hook(lo, hi)` is called as ranges complete.
+
+        Weight gradients run on a second HIP stream (ICAMD_WGRAD_STREAM=0 keeps one stream): a layer's wgrad only needs
+        that layer's output gradient and its saved input, nothing downstream needs its result before the optimizer, and it
+        is MFMA/latency-bound while the BatchNorm-backward passes the main stream runs next are HBM-bound -- side by side
+        they fill both.  The output-gradient buffers rotate through a small pool so the main stream can run ahead; an
+        event per buffer keeps it from overwriting one a pending wgrad still reads."""
         if _FUSED_BNBWD:
             return self._backward_packed_fused(ws, accumulate)
         lib = self.lib
-        s = hip.stream_ptr()
+        main = torch.cuda.current_stream()
+        s = main.cuda_stream
         N = ws["N"]
         acc = int(bool(accumulate))
         wsp, wsb = ws["wgrad_ws"].data_ptr(), ws["wgrad_ws_bytes"]
         bws, bwb = ws["bnb_ws"].data_ptr(), ws["bnb_ws_bytes"]
-        D0, D1, G, T, Y, Y2, DA = (b.data_ptr() for b in self._grad_buffers(ws))
+        bufs = self._grad_buffers(ws)
+        D0, D1, T, DA = (b.data_ptr() for b in bufs[:4])
+        ypool = [b.data_ptr() for b in bufs[4:]]
         hook = self.grad_ready_hook
+        side = self._wgrad_stream() if _WGRAD_STREAM else None
+        ws_side = side.cuda_stream if side is not None else s
+        pending = [None] * len(ypool)     # per pool buffer: event of the last side-stream wgrad reading it
+        state = {"next": 0, "last": None}
 
-        def wgrad(conv, x_ptr, dy_ptr, n, ih, iw):
+        def next_y():
+            k = state["next"]
+            state["next"] = (k + 1) % len(ypool)
+            if pending[k] is not None:
+                main.wait_event(pending[k])
+                pending[k] = None
+            return k
+
+        def wgrad(conv, x_ptr, dy_ptr, n, ih, iw, ybuf=None):
             d = conv.desc(n, ih, iw)
-            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, s),
+            if side is not None:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, ws_side),
                       conv.name + " wgrad")
+            if side is not None:
+                done = torch.cuda.Event()
+                done.record(side)
+                state["last"] = done
+                if ybuf is not None:
+                    pending[ybuf] = done
+
+        def join_side():
+            if state["last"] is not None:
+                main.wait_event(state["last"])
+                state["last"] = None
 
         def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw, addend_bits=None):
             d = conv.desc(n, ih, iw)
@@ -635,6 +673,7 @@ class ResNet:
         hip.check(lib.icamd_colsum(dl, N, self.ncls_p, self.ncls_p, self._gf(self.fc.b), acc, s), "fc bias grad")
         dgrad(self.fc, dl, ws["dpooled"].data_ptr(), None, N, 1, 1)
         if hook:
+            join_side()
             hook(self.fc.w.offset, self.n_params)
         fh, fw = ws["final_hw"]
         dout, other = D0, D1
@@ -653,32 +692,45 @@ class ResNet:
             # last BN (+ residual + ReLU): g = dout * [block output > 0] via the 1-bit mask the forward stored; g itself is
             # never written: the shortcut consumers below re-apply the same bits to `dout`
             mask = b["mask"].data_ptr()
-            bn_bwd(bns[-1], dout, None, b["y"][-1], Y, None, True, mask)
+            yk = next_y()
+            bn_bwd(bns[-1], dout, None, b["y"][-1], ypool[yk], None, True, mask)
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
-                wgrad(convs[i], x_i.data_ptr(), Y, N, *hw_in[i])
-                dgrad(convs[i], Y, DA, None, N, *hw_in[i])
+                wgrad(convs[i], x_i.data_ptr(), ypool[yk], N, *hw_in[i], ybuf=yk)
+                dgrad(convs[i], ypool[yk], DA, None, N, *hw_in[i])
                 # BN + ReLU with no residual in front of the ReLU: mask recomputed from y
-                bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], Y, None, True)
-            wgrad(convs[0], xin.data_ptr(), Y, N, h, w)
+                yk = next_y()
+                bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], ypool[yk], None, True)
+            wgrad(convs[0], xin.data_ptr(), ypool[yk], N, h, w, ybuf=yk)
             if "down_conv" in blk:
-                bn_bwd(blk["down_bn"], dout, None, b["yd"], Y2, None, True, mask)   # "relu" = apply the block's mask bits
-                wgrad(blk["down_conv"], xin.data_ptr(), Y2, N, h, w)
-                dgrad(blk["down_conv"], Y2, T, None, N, h, w)
-                dgrad(convs[0], Y, other, T, N, h, w)
+                y2 = next_y()
+                bn_bwd(blk["down_bn"], dout, None, b["yd"], ypool[y2], None, True, mask)   # "relu" = the block's mask bits
+                wgrad(blk["down_conv"], xin.data_ptr(), ypool[y2], N, h, w, ybuf=y2)
+                dgrad(blk["down_conv"], ypool[y2], T, None, N, h, w)
+                dgrad(convs[0], ypool[yk], other, T, N, h, w)
             else:
-                dgrad(convs[0], Y, other, dout, N, h, w, mask)
+                dgrad(convs[0], ypool[yk], other, dout, N, h, w, mask)
             if hook:
+                join_side()
                 hook(convs[0].w.offset, None)
             dout, other = other, dout
 
         # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
         d0 = self.stem_conv.desc(N, ws["H"], ws["W"])
         hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
-        bn_bwd(self.stem_bn, DA, None, ws["y0"], Y, None, True)
-        wgrad(self.stem_conv, ws["x8"].data_ptr(), Y, N, ws["H"], ws["W"])
+        yk = next_y()
+        bn_bwd(self.stem_bn, DA, None, ws["y0"], ypool[yk], None, True)
+        wgrad(self.stem_conv, ws["x8"].data_ptr(), ypool[yk], N, ws["H"], ws["W"], ybuf=yk)
+        for k in range(len(pending)):     # every buffer is free again when the next backward starts
+            pending[k] = None
+        join_side()
         if hook:
             hook(0, None)
+
+    def _wgrad_stream(self):
+        if getattr(self, "_wg_stream", None) is None:
+            self._wg_stream = torch.cuda.Stream(device=self.device)
+        return self._wg_stream
 
     def _backward_packed_fused(self, ws, accumulate=False):
         """Variant that fuses each BatchNorm backward's mask + reduction pass into the epilogue of the data-gradient
@@ -691,7 +743,7 @@ class ResNet:
         acc = int(bool(accumulate))
         wsp, wsb = ws["wgrad_ws"].data_ptr(), ws["wgrad_ws_bytes"]
         bws, bwb = ws["bnb_ws"].data_ptr(), ws["bnb_ws_bytes"]
-        D0, D1, G, T, Y, Y2, DA = (b.data_ptr() for b in self._grad_buffers(ws))
+        D0, D1, G, T, Y, Y2, DA = (b.data_ptr() for b in self._grad_buffers(ws)[:7])
         hook = self.grad_ready_hook
 
         def wgrad(conv, x_ptr, dy_ptr, n, ih, iw):
