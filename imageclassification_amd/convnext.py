@@ -12,6 +12,7 @@ NHWC activations make every "channels-first LayerNorm" an ordinary row LayerNorm
 convolution on the same tensor (bias fused); the depthwise stencil and the layer-scale tail are dedicated kernels.
 """
 import ctypes
+import os
 import math
 from collections import OrderedDict
 
@@ -404,25 +405,35 @@ class ConvNeXt:
         csp, csb = ws["cs_ws"].data_ptr(), ws["cs_bytes"]
         G = [g.data_ptr() for g in self._scratch(ws)]
 
+        lane = self._side_lane()
+        lane.begin()
+
+        def W(ptr):
+            """`ptr` is about to be overwritten on the main stream: wait for side-lane launches still reading it."""
+            lane.before_write(ptr)
+            return ptr
+
         def gemm_bwd(c, x_ptr, dy_ptr, n, h, w, dx_ptr):
             d = c.desc(n, h, w)
-            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(c.w), acc, wsp, wsb, s), c.name + " wgrad")
+            lane.launch(lambda st_: hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(c.w), acc, wsp, wsb,
+                                                                     st_), c.name + " wgrad"), reads=(dy_ptr,))
             hip.check(lib.icamd_colsum_rows(dy_ptr, n * d.OH * d.OW, c.cout_p, c.cout_p, self._gf(c.b), acc, csp, csb, s),
                       c.name + " bias grad")
             if dx_ptr is not None:
-                hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(c), dx_ptr, None, None, s), c.name + " dgrad")
+                hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(c), W(dx_ptr), None, None, s), c.name + " dgrad")
 
         def ln_bwd(dy_ptr, x, st, wp, bp, dx_ptr, rows, C):
             hip.check(lib.icamd_layernorm_bwd(dy_ptr, x.data_ptr(), st.data_ptr(), st.data_ptr() + 4 * rows, self._pf(wp), None,
-                                              dx_ptr, self._gf(wp), self._gf(bp), rows, C, acc, lnp, lnb, s), wp.name + " bwd")
+                                              W(dx_ptr), self._gf(wp), self._gf(bp), rows, C, acc, lnp, lnb, s), wp.name + " bwd")
 
         dl = self.dims[-1]
         h, w = ws["final_hw"]
         gemm_bwd(self.head, ws["pn"].data_ptr(), ws["dlogits"].data_ptr(), N, 1, 1, G[1])
         ln_bwd(G[1], ws["pool"], ws["st_head"], self.head_nw, self.head_nb, G[2], N, dl)
         dout = G[0]
-        hip.check(lib.icamd_avgpool_bwd(G[2], dout, N, h * w, dl, s), "avgpool bwd")
+        hip.check(lib.icamd_avgpool_bwd(G[2], W(dout), N, h * w, dl, s), "avgpool bwd")
         if hook:
+            lane.join()
             hook(self.head_nw.offset, self.n_params)
         other = G[3]
         for si in range(len(self.stages) - 1, -1, -1):
@@ -431,19 +442,23 @@ class ConvNeXt:
             rows = N * h * w
             for blk, b in zip(reversed(st["blocks"]), reversed(sw["blocks"])):
                 keep = None if b["keep"] is None else b["keep"].data_ptr()
-                hip.check(lib.icamd_layerscale_bwd(dout, b["z2"].data_ptr(), self._pf(blk["gamma"]), keep, G[1],
+                hip.check(lib.icamd_layerscale_bwd(dout, b["z2"].data_ptr(), self._pf(blk["gamma"]), keep, W(G[1]),
                                                    self._gf(blk["gamma"]), rows, dim, h * w, acc, csp, csb, s), "layer scale bwd")
                 gemm_bwd(blk["fc2"], b["a"].data_ptr(), G[1], N, h, w, G[2])                 # G2 = d a
-                hip.check(lib.icamd_gelu_bwd(G[2], b["z1"].data_ptr(), G[4], b["z1"].numel(), s), "gelu bwd")   # G4 = d z1
+                hip.check(lib.icamd_gelu_bwd(G[2], b["z1"].data_ptr(), W(G[4]), b["z1"].numel(), s), "gelu bwd")   # G4 = d z1
                 gemm_bwd(blk["fc1"], b["h"].data_ptr(), G[4], N, h, w, G[1])                 # G1 = d h
                 ln_bwd(G[1], b["d"], b["st"], blk["nw"], blk["nb"], G[2], rows, dim)         # G2 = d (dwconv out)
-                hip.check(lib.icamd_dwconv7_wgrad(b["in"].data_ptr(), G[2], self._gf(blk["dw_w"]), acc, dwp, dwb, N, h, w, dim, s),
-                          blk["name"] + " dw wgrad")
+                bin_ptr, g2, hh, ww_, dd = b["in"].data_ptr(), G[2], h, w, dim
+                dwg = self._gf(blk["dw_w"])
+                lane.launch(lambda st_, bin_ptr=bin_ptr, g2=g2, hh=hh, ww_=ww_, dd=dd, dwg=dwg, nm=blk["name"]: hip.check(
+                    lib.icamd_dwconv7_wgrad(bin_ptr, g2, dwg, acc, dwp, dwb, N, hh, ww_, dd, st_), nm + " dw wgrad"),
+                    reads=(G[2],))
                 hip.check(lib.icamd_colsum_rows(G[2], rows, dim, dim, self._gf(blk["dw_b"]), acc, csp, csb, s), "dw bias grad")
-                hip.check(lib.icamd_dwconv7_dgrad(G[2], self.shadow.data_ptr() + 2 * blk["dw_w"].offset, dout, other, N, h, w, dim,
-                                                  s), blk["name"] + " dw dgrad")             # + residual gradient
+                hip.check(lib.icamd_dwconv7_dgrad(G[2], self.shadow.data_ptr() + 2 * blk["dw_w"].offset, dout, W(other), N, h, w,
+                                                  dim, s), blk["name"] + " dw dgrad")        # + residual gradient
                 dout, other = other, dout
                 if hook:
+                    lane.join()
                     hook(blk["dw_w"].offset, None)
             if si > 0:
                 prev = self.dims[si - 1]
@@ -452,8 +467,16 @@ class ConvNeXt:
                 ln_bwd(G[1], sw["in"], sw["st"], st["ds_nw"], st["ds_nb"], other, N * h * w, prev)
                 dout, other = other, dout
                 if hook:
+                    lane.join()
                     hook(st["ds_nw"].offset, None)
         ln_bwd(dout, ws["s"], ws["st_stem"], self.stem_nw, self.stem_nb, G[1], N * h * w, self.dims[0])
         gemm_bwd(self.stem, ws["x8"].data_ptr(), G[1], N, ws["H"], ws["W"], None)
+        lane.join()
         if hook:
             hook(0, None)
+
+    def _side_lane(self):
+        if getattr(self, "_lane", None) is None:
+            from .streams import SideLane
+            self._lane = SideLane(self.device, os.environ.get("ICAMD_WGRAD_STREAM", "1") != "0")
+        return self._lane
