@@ -433,8 +433,7 @@ class ConvNeXt:
         dout = G[0]
         hip.check(lib.icamd_avgpool_bwd(G[2], W(dout), N, h * w, dl, s), "avgpool bwd")
         if hook:
-            lane.join()
-            hook(self.head_nw.offset, self.n_params)
+            hook(self.head_nw.offset, self.n_params, lane.events())
         other = G[3]
         for si in range(len(self.stages) - 1, -1, -1):
             st, sw = self.stages[si], ws["stages"][si]
@@ -458,8 +457,7 @@ class ConvNeXt:
                                                   dim, s), blk["name"] + " dw dgrad")        # + residual gradient
                 dout, other = other, dout
                 if hook:
-                    lane.join()
-                    hook(blk["dw_w"].offset, None)
+                    hook(blk["dw_w"].offset, None, lane.events())
             if si > 0:
                 prev = self.dims[si - 1]
                 gemm_bwd(st["ds"], sw["ln"].data_ptr(), dout, N, 2 * h, 2 * w, G[1])
@@ -467,8 +465,7 @@ class ConvNeXt:
                 ln_bwd(G[1], sw["in"], sw["st"], st["ds_nw"], st["ds_nb"], other, N * h * w, prev)
                 dout, other = other, dout
                 if hook:
-                    lane.join()
-                    hook(st["ds_nw"].offset, None)
+                    hook(st["ds_nw"].offset, None, lane.events())
         ln_bwd(dout, ws["s"], ws["st_stem"], self.stem_nw, self.stem_nb, G[1], N * h * w, self.dims[0])
         gemm_bwd(self.stem, ws["x8"].data_ptr(), G[1], N, ws["H"], ws["W"], None)
         lane.join()

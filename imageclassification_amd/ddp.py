@@ -53,15 +53,16 @@ class GradReducer:
         self._works = []
         self.launched = []
 
-    def grads_ready_from(self, lo):
-        """Backward reports that every gradient at offset >= lo is final."""
+    def grads_ready_from(self, lo, wait_events=()):
+        """Backward reports that every gradient at offset >= lo is final once the current stream and `wait_events`
+        (events of other streams that also write gradients: the weight-gradient side lane) have been reached."""
         if self.world == 1:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
-            self._launch(self._next)
+            self._launch(self._next, wait_events)
             self._next += 1
 
-    def _launch(self, bi):
+    def _launch(self, bi, wait_events=()):
         lo, hi = self.buckets[bi]
         view = self.flat[lo:hi]
         self.launched.append(bi)
@@ -69,6 +70,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            for e in wait_events:
+                self.comm_stream.wait_event(e)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         else:
@@ -98,7 +101,7 @@ class DistributedDataParallel:
     def __init__(self, module, device_ids=None, find_unused_parameters=False, first_bucket_mb=1.0, bucket_mb=25.0):
         self.module = module
         self.reducer = GradReducer(module.grad_arena, first_bucket_mb, bucket_mb)
-        module.grad_ready_hook = lambda lo, _hi=None: self.reducer.grads_ready_from(lo)
+        module.grad_ready_hook = lambda lo, _hi=None, events=(): self.reducer.grads_ready_from(lo, events)
         # DDP constructor semantics: every rank starts from rank 0's parameters and buffers
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(module.param_arena, src=0)

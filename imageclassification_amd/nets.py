@@ -654,6 +654,11 @@ class ResNet:
                 main.wait_event(state["last"])
                 state["last"] = None
 
+        def side_events():
+            """Events a gradient consumer on ANOTHER stream (the all-reduce) must wait for besides the main stream: the main
+            stream itself keeps running ahead of the weight gradients."""
+            return () if state["last"] is None else (state["last"],)
+
         def dgrad(conv, dy_ptr, dx_ptr, addend, n, ih, iw, addend_bits=None):
             d = conv.desc(n, ih, iw)
             hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(conv), dx_ptr, addend, addend_bits, s),
@@ -673,8 +678,7 @@ class ResNet:
         hip.check(lib.icamd_colsum(dl, N, self.ncls_p, self.ncls_p, self._gf(self.fc.b), acc, s), "fc bias grad")
         dgrad(self.fc, dl, ws["dpooled"].data_ptr(), None, N, 1, 1)
         if hook:
-            join_side()
-            hook(self.fc.w.offset, self.n_params)
+            hook(self.fc.w.offset, self.n_params, side_events())
         fh, fw = ws["final_hw"]
         dout, other = D0, D1
         hip.check(lib.icamd_avgpool_bwd(ws["dpooled"].data_ptr(), dout, N, fh * fw, self.feat_dim, s), "avgpool bwd")
@@ -696,6 +700,8 @@ class ResNet:
             bn_bwd(bns[-1], dout, None, b["y"][-1], ypool[yk], None, True, mask)
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
+                # wgrad first: measured, it overlaps best with the data-gradient kernel of the same layer (issued after it,
+                # i.e. beside the next BatchNorm backward whose 1024 workgroups fill every wave slot, the gain disappears)
                 wgrad(convs[i], x_i.data_ptr(), ypool[yk], N, *hw_in[i], ybuf=yk)
                 dgrad(convs[i], ypool[yk], DA, None, N, *hw_in[i])
                 # BN + ReLU with no residual in front of the ReLU: mask recomputed from y
@@ -711,8 +717,7 @@ class ResNet:
             else:
                 dgrad(convs[0], ypool[yk], other, dout, N, h, w, mask)
             if hook:
-                join_side()
-                hook(convs[0].w.offset, None)
+                hook(convs[0].w.offset, None, side_events())
             dout, other = other, dout
 
         # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
@@ -723,9 +728,9 @@ class ResNet:
         wgrad(self.stem_conv, ws["x8"].data_ptr(), ypool[yk], N, ws["H"], ws["W"], ybuf=yk)
         for k in range(len(pending)):     # every buffer is free again when the next backward starts
             pending[k] = None
-        join_side()
         if hook:
-            hook(0, None)
+            hook(0, None, side_events())
+        join_side()
 
     def _wgrad_stream(self):
         if getattr(self, "_wg_stream", None) is None:

@@ -46,6 +46,10 @@ class SideLane:
             if ev is not None:
                 self.main.wait_event(ev)
 
+    def events(self):
+        """Events a consumer on another stream (the gradient all-reduce) must wait for besides the main stream."""
+        return () if self._last is None else (self._last,)
+
     def join(self):
         """Main stream waits for everything launched on the side lane so far (before a gradient hook / the optimizer)."""
         if self._last is not None:

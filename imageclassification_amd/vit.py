@@ -410,8 +410,7 @@ class VisionTransformer:
         lin_bwd(self.head, ws["pooled"], ws["dlogits"], B, ws["dpooled"])
         ln_bwd(ws["dpooled"], ws["cls_rows"], ws["stf"], self.p_nw, self.p_nb, None, ws["dcls"], B)
         if hook:
-            lane.join()
-            hook(self.p_nw.offset, self.n_params)
+            hook(self.p_nw.offset, self.n_params, lane.events())
         dx = g0
         hip.check(lib.icamd_fill_zero(dx.data_ptr(), dx.numel() * 2, s), "zero")
         hip.check(lib.icamd_strided_rows_copy(ws["dcls"].data_ptr(), D, dx.data_ptr(), T * D, B, D, s), "cls scatter")
@@ -438,8 +437,7 @@ class VisionTransformer:
             ln_bwd(dh, b["x"], b["st1"], blk["n1w"], blk["n1b"], dx1, dxin, M)    # dx_in = LN1'(dh) + dx1
             dx = dxin
             if hook:
-                lane.join()
-                hook(blk["n1w"].offset, None)
+                hook(blk["n1w"].offset, None, lane.events())
         # tokens -> cls_token, pos_embed, patches
         hip.check(lib.icamd_batch_sum(dx.data_ptr(), T * D, B, T * D, self._gf(self.p_pos), acc, s), "pos_embed grad")
         hip.check(lib.icamd_batch_sum(dx.data_ptr(), T * D, B, D, self._gf(self.p_cls), acc, s), "cls_token grad")

@@ -1,0 +1,93 @@
+"""Worker of tests/test_ddp_gpu.py: one of two ranks sharing the single GPU (gloo carries the collectives, so the test
+needs no second device; the product's reducer, side streams and hooks are exactly the ones the RCCL path uses).
+
+Checks, per model family: the gradients the bucketed/overlapped reducer leaves in the arena, times 1/world, equal the mean
+of the ranks' local gradients (computed without the reducer on the same batch); and after two train_one_epoch steps every
+rank holds bit-identical parameters."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def build(arch, C):
+    if arch.startswith("resnet"):
+        from imageclassification_amd.nets import ResNet
+        return ResNet(arch, C, seed=5), 64
+    if arch.startswith("vit"):
+        from imageclassification_amd.vit import VisionTransformer
+        return VisionTransformer(arch, C, img_size=32, seed=5), 32
+    from imageclassification_amd.convnext import ConvNeXt
+    return ConvNeXt(arch, C, drop_path_rate=0.0, seed=5), 64
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda")
+    from imageclassification_amd import hip
+    from imageclassification_amd.ddp import DistributedDataParallel
+    from imageclassification_amd.engine import train_one_epoch
+    from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
+    from imageclassification_amd.optim_factory import create_optimizer
+    from imageclassification_amd.utils import NativeScalerWithGradNormCount
+    lib = hip.load()
+    C, B = 10, 8
+    for arch in sys.argv[1:]:
+        net, hw = build(arch, C)
+        ddp = DistributedDataParallel(net, first_bucket_mb=0.05, bucket_mb=0.5)   # many buckets on a small model
+        assert len(ddp.reducer.buckets) >= 3, len(ddp.reducer.buckets)
+        g = torch.Generator().manual_seed(100 + rank)
+        x = torch.randn(B, 3, hw, hw, generator=g).to(dev)
+        y = torch.randint(0, C, (B,), generator=g).to(dev)
+
+        def fwd_bwd():
+            ws = net.pack(x)
+            logits = net.forward_packed(ws)
+            hip.check(lib.icamd_softmax_xent(logits.data_ptr(), net.ncls_p, B, C, y.data_ptr(), None, 1.0, 0.1, 1.0 / B,
+                                             ws["loss_rows"].data_ptr(), ws["pred"].data_ptr(), ws["dlogits"].data_ptr(),
+                                             hip.stream_ptr()), "xent")
+            net.backward_packed(ws)
+
+        hook = net.grad_ready_hook
+        net.grad_ready_hook = None
+        fwd_bwd()
+        torch.cuda.synchronize()
+        local = net.grad_arena.clone()
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        mean = sum(t.double() for t in gathered) / world
+        net.grad_ready_hook = hook
+        ddp.reducer.reset()
+        fwd_bwd()
+        ddp.reducer.finish()
+        torch.cuda.synchronize()
+        got = net.grad_arena.double() * ddp.reducer.grad_scale
+        err = (got - mean).abs().max().item()
+        scale = mean.abs().max().item()
+        assert err <= 1e-6 * max(scale, 1e-3), (arch, err, scale)
+        assert sorted(ddp.reducer.launched) == list(range(len(ddp.reducer.buckets)))
+
+        # two optimizer steps through the drop-in boundary: ranks stay bit-identical
+        opt = create_optimizer("adamw", 1e-3, 0.05, net)
+        data = [(torch.randn(B, 3, hw, hw, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(2)]
+        train_one_epoch(ddp, LabelSmoothingCrossEntropy(0.1), data, opt, dev, 0, NativeScalerWithGradNormCount(), None, None,
+                        None, start_steps=0, lr_schedule_values=[1e-3, 1e-3], wd_schedule_values=[0.05, 0.05],
+                        num_training_steps_per_epoch=2, update_freq=1, use_amp=True, num_classes=C)
+        torch.cuda.synchronize()
+        mine = net.param_arena.clone()
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1]), arch
+        if rank == 0:
+            print(f"ddp-ok {arch} buckets={len(ddp.reducer.buckets)} grad_err={err:.2e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
