@@ -26,13 +26,15 @@ namespace {
 constexpr int HD = 64;          // head dimension
 constexpr int ROWB = HD * 2;    // bytes per LDS row
 
-// LDS images of a [rows][64] bf16 matrix (128 B rows)
-//  "row" image: read 16 B chunks of one row per lane (ds_read_b128): chunk ^= (row>>1)&7
-//  "tr"  image: read 4-row x 16-column blocks transposed (ds_read_b64_tr_b16): 32 B block ^= (row>>1)&3
-__device__ __forceinline__ int row_img(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS image of a [rows][64] bf16 matrix (128 B rows): the 32 B column block is XOR-ed with (row>>1)&3.  ONE image
+// serves both access patterns without bank conflicts: 4-row x 16-column blocks read transposed (ds_read_b64_tr_b16; a
+// 32-lane half touches 8 rows x 32 B = 2 row parities x 4 block keys) and 16 B chunks of one row per lane
+// (ds_read_b128; its 16-lane groups {0-3, 12-15, 20-27}, ... hold rows of four different keys for the even chunk and
+// of four for the odd one).  Keeping a single image per matrix is what lets two workgroups share a CU's 160 KB.
 __device__ __forceinline__ int tr_img(int row, int chunk) {
   return row * ROWB + ((((chunk >> 1) ^ ((row >> 1) & 3))) << 5) + ((chunk & 1) << 4);
 }
+__device__ __forceinline__ int row_img(int row, int chunk) { return tr_img(row, chunk); }
 
 __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* img, int row0, int row1, int dblk, int lane) {
   const int c = lane & 15, q = c >> 2, pq = c & 3;
@@ -51,16 +53,14 @@ __device__ __forceinline__ bf16x8 pack_acc2(const f32x4& lo, const f32x4& hi) {
   return r;
 }
 
-// stage a [T][64] slice (rows beyond T and up to `rows_pad` zero) of a token matrix into one or two LDS images
-template <bool ROWIMG, bool TRIMG>
+// stage a [T][64] slice (rows beyond T and up to `rows_pad` zero) of a token matrix into its LDS image
 __device__ __forceinline__ void stage_matrix(const bf16_t* __restrict__ src, long long ld, int T, int rows_pad,
-                                             unsigned char* img_row, unsigned char* img_tr) {
+                                             unsigned char* img) {
   for (int i = threadIdx.x; i < rows_pad * 8; i += 256) {
     const int r = i >> 3, ch = i & 7;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r < T) v = *(const u32x4*)(src + (long long)r * ld + ch * 8);
-    if constexpr (ROWIMG) *(u32x4*)(img_row + row_img(r, ch)) = v;
-    if constexpr (TRIMG) *(u32x4*)(img_tr + tr_img(r, ch)) = v;
+    *(u32x4*)(img + tr_img(r, ch)) = v;
   }
 }
 
@@ -88,7 +88,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // forward
 // ----------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int T, int H, float scale) {
   constexpr int NPAIR = (NKB + 1) / 2;
   constexpr int RP = NPAIR * 32;   // padded key rows (zeros beyond T)
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const bf16_t* qb_ = base + h * HD;
   const bf16_t* kb_ = base + (long long)H * HD + h * HD;
   const bf16_t* vb_ = base + 2ll * H * HD + h * HD;
-  stage_matrix<true, false>(kb_, ld, T, RP, Kr, nullptr);
-  stage_matrix<false, true>(vb_, ld, T, RP, nullptr, Vt);
+  stage_matrix(kb_, ld, T, RP, Kr);
+  stage_matrix(vb_, ld, T, RP, Vt);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   for (int qblk = wave; qblk < NKB; qblk += 4) {
@@ -170,15 +170,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 // backward, part 1: dQ (query on the lane) and delta = rowsum(dO * O)
 // ----------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int T,
                                                           int H, float scale) {
   constexpr int NPAIR = (NKB + 1) / 2;
   constexpr int RP = NPAIR * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char Kr[RP * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char Kt[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Kr[RP * ROWB];   // read by rows (S^T) and transposed (dQ^T)
   __shared__ __attribute__((aligned(16))) unsigned char Vr[RP * ROWB];
+  const unsigned char* Kt = Kr;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const long long ld = 3ll * H * HD, ldo = (long long)H * HD;
   const bf16_t* base = qkv + (long long)b * T * ld;
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* vb_ = base + 2ll * H * HD + h * HD;
   const bf16_t* ob_ = out + (long long)b * T * ldo + h * HD;
   const bf16_t* dob_ = dout + (long long)b * T * ldo + h * HD;
-  stage_matrix<true, true>(kb_, ld, T, RP, Kr, Kt);
-  stage_matrix<true, false>(vb_, ld, T, RP, Vr, nullptr);
+  stage_matrix(kb_, ld, T, RP, Kr);
+  stage_matrix(vb_, ld, T, RP, Vr);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   for (int qblk = wave; qblk < NKB; qblk += 4) {
@@ -205,32 +205,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     dl = group_sum(dl);
     const float lq = qrow < T ? lse[((long long)b * H + h) * T + qrow] : 0.f;
     if (g == 0 && qrow < T) delta[((long long)b * H + h) * T + qrow] = dl;
-    f32x4 ds[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Kr + row_img(kb * 16 + c, ks * 4 + g));
-        const bf16x8 vf = *(const bf16x8*)(Vr + row_img(kb * 16 + c, ks * 4 + g));
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T[key][query]
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T[key][query]
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb * 16 + 4 * g + r;
-        const float p = (key < T && qrow < T) ? __expf(s[r] * scale - lq) : 0.f;
-        ds[kb][r] = p * (dp[r] - dl) * scale;
-      }
-    }
-    // dQ^T[d][query] = sum_key K^T[d][key] dS^T[key][query]
+    // per pair of key blocks: S^T and dP^T (key on the accumulator rows, query on the lane) -> dS^T -> straight into
+    // dQ^T[d][query] += K^T[d][key] dS^T[key][query]; nothing but dq[] lives across iterations (the loop is kept rolled so
+    // the 13-block instance stays within 256 registers at two workgroups per CU)
     f32x4 dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int pp = 0; pp < NPAIR; ++pp) {
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 dsf = pack_acc2(ds[2 * pp], (2 * pp + 1 < NKB) ? ds[2 * pp + 1] : zero);
+      f32x4 ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kb = 2 * pp + u;   // rows beyond NKB*16 are zero in the images
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(Kr + row_img(kb * 16 + c, ks * 4 + g));
+          const bf16x8 vf = *(const bf16x8*)(Vr + row_img(kb * 16 + c, ks * 4 + g));
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T[key][query]
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T[key][query]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 16 + 4 * g + r;
+          const float p = (key < T && qrow < T) ? __expf(s[r] * scale - lq) : 0.f;
+          ds2[u][r] = p * (dp[r] - dl) * scale;
+        }
+      }
+      const bf16x8 dsf = pack_acc2(ds2[0], ds2[1]);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const bf16x8 ktf = tr_pair(Kt, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, db, lane);   // A[d = db*16 + c][keys]
@@ -254,15 +256,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // backward, part 2: dK and dV (key on the lane; a wave owns whole key blocks and walks all queries)
 // ----------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv, int T, int H, float scale) {
   constexpr int NPAIR = (NKB + 1) / 2;
   constexpr int RP = NPAIR * 32;
-  __shared__ __attribute__((aligned(16))) unsigned char Qr[RP * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char Qt[RP * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char Dr[RP * ROWB];
-  __shared__ __attribute__((aligned(16))) unsigned char Dt[RP * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char Qr[RP * ROWB];   // each read by rows (S, dP) and transposed
+  __shared__ __attribute__((aligned(16))) unsigned char Dr[RP * ROWB];   // (dK^T, dV^T)
+  const unsigned char* Qt = Qr;
+  const unsigned char* Dt = Dr;
   __shared__ float s_lse[RP], s_dl[RP];
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const long long ld = 3ll * H * HD, ldo = (long long)H * HD;
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const bf16_t* kb_ = base + (long long)H * HD + h * HD;
   const bf16_t* vb_ = base + 2ll * H * HD + h * HD;
   const bf16_t* dob_ = dout + (long long)b * T * ldo + h * HD;
-  stage_matrix<true, true>(qb_, ld, T, RP, Qr, Qt);
-  stage_matrix<true, true>(dob_, ldo, T, RP, Dr, Dt);
+  stage_matrix(qb_, ld, T, RP, Qr);
+  stage_matrix(dob_, ldo, T, RP, Dr);
   for (int i = threadIdx.x; i < RP; i += 256) {
     s_lse[i] = i < T ? lse[((long long)b * H + h) * T + i] : 0.f;
     s_dl[i] = i < T ? delta[((long long)b * H + h) * T + i] : 0.f;
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
-#pragma unroll
+#pragma unroll 1
     for (int pp = 0; pp < NPAIR; ++pp) {
       f32x4 p2[2], ds2[2];
 #pragma unroll
