@@ -24,6 +24,14 @@
 namespace {
 
 constexpr int HD = 64;          // head dimension
+#ifndef ICAMD_ATTN_BWD_THREADS
+#define ICAMD_ATTN_BWD_THREADS 512
+#endif
+#ifndef ICAMD_ATTN_FWD_THREADS
+#define ICAMD_ATTN_FWD_THREADS 512
+#endif
+constexpr int FWD_THREADS = ICAMD_ATTN_FWD_THREADS;
+constexpr int BWD_THREADS = ICAMD_ATTN_BWD_THREADS;   // backward workgroups: 8 waves share one pair of LDS images
 constexpr int ROWB = HD * 2;    // bytes per LDS row
 
 // LDS image of a [rows][64] bf16 matrix (128 B rows): the 32 B column block is XOR-ed with (row>>1)&3.  ONE image
@@ -56,7 +64,7 @@ __device__ __forceinline__ bf16x8 pack_acc2(const f32x4& lo, const f32x4& hi) {
 // stage a [T][64] slice (rows beyond T and up to `rows_pad` zero) of a token matrix into its LDS image
 __device__ __forceinline__ void stage_matrix(const bf16_t* __restrict__ src, long long ld, int T, int rows_pad,
                                              unsigned char* img) {
-  for (int i = threadIdx.x; i < rows_pad * 8; i += 256) {
+  for (int i = threadIdx.x; i < rows_pad * 8; i += blockDim.x) {
     const int r = i >> 3, ch = i & 7;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (r < T) v = *(const u32x4*)(src + (long long)r * ld + ch * 8);
@@ -88,7 +96,7 @@ __device__ __forceinline__ float group_sum(float v) {
 // forward
 // ----------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int T, int H, float scale) {
   constexpr int NPAIR = (NKB + 1) / 2;
   constexpr int RP = NPAIR * 32;   // padded key rows (zeros beyond T)
@@ -104,52 +112,62 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   stage_matrix(vb_, ld, T, RP, Vt);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  for (int qblk = wave; qblk < NKB; qblk += 4) {
+  for (int qblk = wave; qblk < NKB; qblk += FWD_THREADS / 64) {
     const int qrow = qblk * 16 + c;
     bf16x8 qf[2];
     load_rowfrag(qb_, ld, qrow, T, g, qf);
-    f32x4 s[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Kr + row_img(kb * 16 + c, ks * 4 + g));
-        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);   // S^T[key][query]
-      }
-    }
-    // lane (c, g) now holds, for query c, keys kb*16 + 4g + r
-    float m = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb * 16 + 4 * g + r;
-        s[kb][r] = key < T ? s[kb][r] * scale : -INFINITY;
-        m = fmaxf(m, s[kb][r]);
-      }
-    m = group_max(m);
-    float l = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s[kb][r] = __expf(s[kb][r] - m); l += s[kb][r]; }
-    l = group_sum(l);
-    if (g == 0 && qrow < T) lse[((long long)b * H + h) * T + qrow] = m + __logf(l);
-    // O[query][d] = sum_key P[query][key] V[key][d]
+    // Online softmax over pairs of key blocks (rolled loop: only the running max m, the per-lane partial sum l and the
+    // 16 output accumulators live across iterations, so eight waves fit the register file four to a SIMD).
+    // Lane (c, g) holds, for query c, the keys kb*16 + 4g + r of each S^T tile.
+    float m = -INFINITY, l = 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
     for (int pp = 0; pp < NPAIR; ++pp) {
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      const bf16x8 pf = pack_acc2(s[2 * pp], (2 * pp + 1 < NKB) ? s[2 * pp + 1] : zero);
+      f32x4 s2[2];
+      float pm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kb = 2 * pp + u;
+        f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(Kr + row_img(kb * 16 + c, ks * 4 + g));
+          sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sv, 0, 0, 0);   // S^T[key][query]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb * 16 + 4 * g + r;
+          s2[u][r] = key < T ? sv[r] * scale : -INFINITY;
+          pm = fmaxf(pm, s2[u][r]);
+        }
+      }
+      const float m_new = fmaxf(m, group_max(pm));   // finite from the first pair on (key 0 exists)
+      const float alpha = __expf(m - m_new);         // 0 on the first pair
+      float ps = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s2[u][r] = __expf(s2[u][r] - m_new); ps += s2[u][r]; }
+      l = l * alpha + ps;
+      m = m_new;
+      // the accumulators hold O[query 4g+r][d]: rescale by that query's alpha (held by the lanes with c == 4g+r)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db][r] *= ar;
+      }
+      const bf16x8 pf = pack_acc2(s2[0], s2[1]);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const bf16x8 vf = tr_pair(Vt, 32 * pp + 4 * g, 32 * pp + 16 + 4 * g, db, lane);
         o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[db], 0, 0, 0);   // D[query 4g+r][d = db*16 + c]
       }
     }
+    l = group_sum(l);
+    if (g == 0 && qrow < T) lse[((long long)b * H + h) * T + qrow] = m + __logf(l);
     const float inv_l = 1.f / l;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 // backward, part 1: dQ (query on the lane) and delta = rowsum(dO * O)
 // ----------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(BWD_THREADS, BWD_THREADS / 128) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int T,
                                                           int H, float scale) {
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   stage_matrix(vb_, ld, T, RP, Vr);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  for (int qblk = wave; qblk < NKB; qblk += 4) {
+  for (int qblk = wave; qblk < NKB; qblk += BWD_THREADS / 64) {
     const int qrow = qblk * 16 + c;
     bf16x8 qf[2], dof[2], of[2];
     load_rowfrag(qb_, ld, qrow, T, g, qf);
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // backward, part 2: dK and dV (key on the lane; a wave owns whole key blocks and walks all queries)
 // ----------------------------------------------------------------------------------------------------------------
 template <int NKB>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(BWD_THREADS, BWD_THREADS / 128) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv, int T, int H, float scale) {
   constexpr int NPAIR = (NKB + 1) / 2;
@@ -275,13 +293,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   const bf16_t* dob_ = dout + (long long)b * T * ldo + h * HD;
   stage_matrix(qb_, ld, T, RP, Qr);
   stage_matrix(dob_, ldo, T, RP, Dr);
-  for (int i = threadIdx.x; i < RP; i += 256) {
+  for (int i = threadIdx.x; i < RP; i += BWD_THREADS) {
     s_lse[i] = i < T ? lse[((long long)b * H + h) * T + i] : 0.f;
     s_dl[i] = i < T ? delta[((long long)b * H + h) * T + i] : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  for (int kblk = wave; kblk < NKB; kblk += 4) {
+  for (int kblk = wave; kblk < NKB; kblk += BWD_THREADS / 64) {
     const int krow = kblk * 16 + c;
     bf16x8 kf[2], vf[2];
     load_rowfrag(kb_, ld, krow, T, g, kf);
@@ -340,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 int icamd_attention_fwd_launch(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T, int H, float scale, hipStream_t s) {
   const dim3 grid((unsigned)(B * H));
-  if (T <= 64) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), 0, s, qkv, out, lse, T, H, scale);
-  else if (T <= 208) hipLaunchKernelGGL(attn_fwd_kernel<13>, grid, dim3(256), 0, s, qkv, out, lse, T, H, scale);
+  if (T <= 64) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(FWD_THREADS), 0, s, qkv, out, lse, T, H, scale);
+  else if (T <= 208) hipLaunchKernelGGL(attn_fwd_kernel<13>, grid, dim3(FWD_THREADS), 0, s, qkv, out, lse, T, H, scale);
   else return ICAMD_ERR_UNSUPPORTED;
   return icamd_launch_status();
 }
@@ -350,11 +368,11 @@ int icamd_attention_bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_
                                bf16_t* dqkv, int B, int T, int H, float scale, hipStream_t s) {
   const dim3 grid((unsigned)(B * H));
   if (T <= 64) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(256), 0, s, qkv, out, dout, lse, delta, dqkv, T, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(BWD_THREADS), 0, s, qkv, out, dout, lse, delta, dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid, dim3(BWD_THREADS), 0, s, qkv, dout, lse, delta, dqkv, T, H, scale);
   } else if (T <= 208) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<13>, grid, dim3(256), 0, s, qkv, out, dout, lse, delta, dqkv, T, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<13>, grid, dim3(256), 0, s, qkv, dout, lse, delta, dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<13>, grid, dim3(BWD_THREADS), 0, s, qkv, out, dout, lse, delta, dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<13>, grid, dim3(BWD_THREADS), 0, s, qkv, dout, lse, delta, dqkv, T, H, scale);
   } else {
     return ICAMD_ERR_UNSUPPORTED;
   }
