@@ -415,10 +415,9 @@ class ConvNeXt:
 
         def gemm_bwd(c, x_ptr, dy_ptr, n, h, w, dx_ptr):
             d = c.desc(n, h, w)
-            lane.launch(lambda st_: hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(c.w), acc, wsp, wsb,
-                                                                     st_), c.name + " wgrad"), reads=(dy_ptr,))
-            hip.check(lib.icamd_colsum_rows(dy_ptr, n * d.OH * d.OW, c.cout_p, c.cout_p, self._gf(c.b), acc, csp, csb, s),
-                      c.name + " bias grad")
+            lane.launch(lambda st_: hip.check(lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), x_ptr, dy_ptr, self._gf(c.w),
+                                                                          self._gf(c.b), acc, wsp, wsb, st_),
+                                              c.name + " wgrad+bias"), reads=(dy_ptr,))
             if dx_ptr is not None:
                 hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(c), W(dx_ptr), None, None, s), c.name + " dgrad")
 

@@ -296,12 +296,27 @@ size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
   if (M >= (1ll << 30)) return 0;
   const int Ktot = d->KH * d->KW * d->Cin;
   icamd_wgrad_plan((int)M, d->Cout, Ktot, &S, &rows);
-  return (size_t)S * d->Cout * Ktot * sizeof(float);
+  return (size_t)S * d->Cout * ((size_t)Ktot + 1) * sizeof(float);   // filter slabs + one bias row per split
 }
+
+static int wgrad_impl(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_WGRAD, stream);
+  return wgrad_impl(d, x, dy, dw, nullptr, accumulate, workspace, workspace_bytes, stream);
+}
+
+int icamd_conv2d_wgrad_bias(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                            int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_WGRAD, stream);
+  if (dbias == nullptr) return ICAMD_ERR_BAD_ARG;
+  return wgrad_impl(d, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_impl(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias, int accumulate,
+                      void* workspace, size_t workspace_bytes, void* stream) {
   if (!conv_desc_ok(d) || x == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
   const size_t need = icamd_conv2d_wgrad_workspace_bytes(d);
   if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
@@ -312,9 +327,12 @@ int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, 
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.M = d->N * d->OH * d->OW; p.Ktot = d->KH * d->KW * d->Cin;
   icamd_wgrad_plan(p.M, p.Cout, p.Ktot, &p.S, &p.rows_per_split);
+  if (dbias != nullptr) p.bias_slab = p.slab + (size_t)p.S * p.Cout * p.Ktot;
   int rc = icamd_wgrad_launch(p, (hipStream_t)stream);
   if (rc) return rc;
-  return icamd_slab_reduce_launch(p.slab, dw, (long long)p.Cout * p.Ktot, p.S, accumulate, (hipStream_t)stream);
+  rc = icamd_slab_reduce_launch(p.slab, dw, (long long)p.Cout * p.Ktot, p.S, accumulate, (hipStream_t)stream);
+  if (rc || dbias == nullptr) return rc;
+  return icamd_slab_reduce_launch(p.bias_slab, dbias, (long long)p.Cout, p.S, accumulate, (hipStream_t)stream);
 }
 
 int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,

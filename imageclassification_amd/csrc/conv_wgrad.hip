@@ -137,6 +137,14 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
   for (int i = 0; i < KR; ++i)
 #pragma unroll
     for (int j = 0; j < CR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Bias gradient (column sums of dY) for free: the workgroups of the first filter-column tile multiply their dY
+  // fragments once more by an all-ones operand (every accumulator row then holds sum_m dY[m][co]); one wave per dY
+  // fragment column does it.  +CR MFMAs per 16*CR on 1/ntiles_k of the workgroups instead of a separate pass over dY.
+  const bool do_bias = p.bias_slab != nullptr && tile_k == 0 && wk == 0;   // wave-uniform
+  f32x4 bacc[CR];
+#pragma unroll
+  for (int j = 0; j < CR; ++j) bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 
   // transposed-read lane roles: 16-lane group g reads reduction rows 8g..8g+7 (two 4-row blocks),
   // lane 4q+pq of the group addresses row q, columns 4pq..4pq+3 of the 16-column block
@@ -167,6 +175,10 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
 #pragma unroll
         for (int j = 0; j < CR; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < CR; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[j], bacc[j], 0, 0, 0);
+      }
     }
   };
   if constexpr (NSTAGE == 2) {
@@ -197,6 +209,13 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
       const int co = c0 + (wc * CR + j) * 16 + (lane & 15);
       if (kk < p.Ktot && co < p.Cout) *(f32x4*)(slab + (long long)co * p.Ktot + kk) = acc[i][j];
     }
+  if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+      const int co = c0 + (wc * CR + j) * 16 + (lane & 15);
+      if (co < p.Cout) p.bias_slab[(long long)split * p.Cout + co] = bacc[j][0];
+    }
+  }
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]; 16 B per lane; fixed summation order.

@@ -54,6 +54,7 @@ struct WgradParams {
   const bf16_t* x;    // [N, IH, IW, Cin]
   const bf16_t* dy;   // [N, OH, OW, Cout]
   float* slab;        // [S][Cout][Ktot] partial sums
+  float* bias_slab;   // optional [S][Cout] partial column sums of dy (bias gradient)
   int N, IH, IW, Cin, OH, OW, Cout;
   int KH, KW, stride, pad;
   int M, Ktot;        // N*OH*OW ; KH*KW*Cin

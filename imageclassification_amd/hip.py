@@ -50,6 +50,7 @@ _SIGNATURES = {
     "icamd_conv2d_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, POINTER(BnBwdFuse), _P]),
     "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "icamd_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "icamd_conv2d_wgrad_bias": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "icamd_filter_transpose": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "icamd_filter_transpose_tiled": (c_int, [_P, _P, _P, _P, c_int, _P]),
     "icamd_bn_workspace_bytes": (c_size_t, [c_int]),

@@ -390,11 +390,9 @@ class VisionTransformer:
             """weight, bias gradients (+ data gradient into dx when given) of y = x W^T + b.  The weight gradient goes to
             the side lane (streams.py); `dy` is protected from being overwritten until it has been read."""
             d = l.desc(rows)
-            lane.launch(lambda st: hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
-                                                                    self._gf(l.w), acc, wsp, wsb, st), l.name + " wgrad"),
-                        reads=(dy.data_ptr(),))
-            hip.check(lib.icamd_colsum_rows(dy.data_ptr(), rows, l.cout_p, l.cout_p, self._gf(l.b), acc, csp, csb, s),
-                      l.name + " bias grad")
+            lane.launch(lambda st: hip.check(lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), x.data_ptr(), dy.data_ptr(),
+                                                                         self._gf(l.w), self._gf(l.b), acc, wsp, wsb, st),
+                                             l.name + " wgrad+bias"), reads=(dy.data_ptr(),))
             if dx is not None:
                 lane.before_write(dx.data_ptr())
                 hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), self._wt(l), dx.data_ptr(), None, None, s),
@@ -445,10 +443,9 @@ class VisionTransformer:
         hip.check(lib.icamd_strided_rows_copy(dx.data_ptr() + 2 * D, T * D, dpatch.data_ptr(), (T - 1) * D, B, (T - 1) * D, s),
                   "patch grads")
         dpe = self._pe_desc(B)
-        lane.launch(lambda st: hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(dpe), ws["x8"].data_ptr(), dpatch.data_ptr(),
-                                                                self._gf(self.pe_w), acc, wsp, wsb, st), "patch_embed wgrad"))
-        hip.check(lib.icamd_colsum_rows(dpatch.data_ptr(), B * (T - 1), D, D, self._gf(self.pe_b), acc, csp, csb, s),
-                  "patch_embed bias grad")
+        lane.launch(lambda st: hip.check(lib.icamd_conv2d_wgrad_bias(ctypes.byref(dpe), ws["x8"].data_ptr(), dpatch.data_ptr(),
+                                                                     self._gf(self.pe_w), self._gf(self.pe_b), acc, wsp, wsb,
+                                                                     st), "patch_embed wgrad+bias"))
         lane.join()
         if hook:
             hook(0, None)

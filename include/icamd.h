@@ -86,6 +86,11 @@ size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d);
 /* dw (fp32 [Cout][KH][KW][Cin]) = (accumulate ? dw : 0) + sum over pixels of dy (x) x */
 int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Same, and the bias gradient dbias[co] = sum_m dy[m][co] (Cout floats, (+)= per `accumulate`) computed inside the same
+ * kernel from the dy fragments it already holds (replaces a separate column-sum pass over dy; nn.Linear / conv biases of
+ * ViT and ConvNeXt).  Same workspace. */
+int icamd_conv2d_wgrad_bias(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                            int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* table-driven batched filter transpose [Cout][T][Cin] -> [Cin][T][Cout] (bf16).
  * descs: int64[nlayers][8] = {src_off, dst_off, Cout, T, Cin, 0,0,0} (element offsets);

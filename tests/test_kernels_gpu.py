@@ -279,6 +279,19 @@ def test_conv_wgrad(lib, case):
     # too-small workspace is refused, not overrun
     assert lib.icamd_conv2d_wgrad(ctypes.byref(d), hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw), 0, hip.ptr(ws), wsb - 1,
                                   hip.stream_ptr()) == 3
+    # fused bias gradient: column sums of dy out of the same kernel (fp64 reference), with and without accumulation
+    db = torch.full((Cout,), 3.0, device=DEV)
+    dw.fill_(7.0)
+    assert lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw), hip.ptr(db), 0, hip.ptr(ws),
+                                       wsb, hip.stream_ptr()) == 0
+    sync()
+    bref = dy.double().reshape(-1, Cout).sum(0).float()
+    assert R.rel_l2(dw.cpu(), ref) <= 1e-4
+    assert torch.allclose(db.cpu(), bref, rtol=1e-4, atol=1e-3 * float(bref.abs().max() + 1))
+    assert lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw), hip.ptr(db), 1, hip.ptr(ws),
+                                       wsb, hip.stream_ptr()) == 0
+    sync()
+    assert torch.allclose(db.cpu(), 2 * bref, rtol=1e-4, atol=2e-3 * float(bref.abs().max() + 1))
 
 
 def test_filter_transpose(lib):
