@@ -367,8 +367,9 @@ class ConvNeXt:
                 hip.check(lib.icamd_dwconv7_fwd(x.data_ptr(), self.shadow.data_ptr() + 2 * blk["dw_w"].offset,
                                                 self._pf(blk["dw_b"]), b["d"].data_ptr(), N, h, w, dim, s), blk["name"] + " dw")
                 self._ln(b["d"], blk["nw"], blk["nb"], b["h"], b["st"], rows, dim, s)
-                self._conv(blk["fc1"], b["h"].data_ptr(), b["z1"], N, h, w, s)
-                hip.check(lib.icamd_gelu_fwd(b["z1"].data_ptr(), b["a"].data_ptr(), b["z1"].numel(), s), "gelu")
+                c1 = blk["fc1"]                                                   # z1 = pwconv1(h), a = gelu(z1): one kernel
+                hip.check(lib.icamd_conv2d_fwd_gelu(ctypes.byref(c1.desc(N, h, w)), b["h"].data_ptr(), self._w(c1),
+                                                    b["z1"].data_ptr(), b["a"].data_ptr(), self._pf(c1.b), s), c1.name + " + gelu")
                 self._conv(blk["fc2"], b["a"].data_ptr(), b["z2"], N, h, w, s)
                 keep = None
                 if self.training and blk["rate"] > 0.0:
@@ -413,13 +414,16 @@ class ConvNeXt:
             lane.before_write(ptr)
             return ptr
 
-        def gemm_bwd(c, x_ptr, dy_ptr, n, h, w, dx_ptr):
+        def gemm_bwd(c, x_ptr, dy_ptr, n, h, w, dx_ptr, gelu_z=None):
             d = c.desc(n, h, w)
             lane.launch(lambda st_: hip.check(lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), x_ptr, dy_ptr, self._gf(c.w),
                                                                           self._gf(c.b), acc, wsp, wsb, st_),
                                               c.name + " wgrad+bias"), reads=(dy_ptr,))
-            if dx_ptr is not None:
+            if dx_ptr is not None and gelu_z is None:
                 hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy_ptr, self._wt(c), W(dx_ptr), None, None, s), c.name + " dgrad")
+            elif dx_ptr is not None:   # dx = (dy W) * gelu'(z) in the data-gradient kernel's store pass
+                hip.check(lib.icamd_conv2d_dgrad_gelu(ctypes.byref(d), dy_ptr, self._wt(c), gelu_z, W(dx_ptr), s),
+                          c.name + " dgrad + gelu bwd")
 
         def ln_bwd(dy_ptr, x, st, wp, bp, dx_ptr, rows, C):
             hip.check(lib.icamd_layernorm_bwd(dy_ptr, x.data_ptr(), st.data_ptr(), st.data_ptr() + 4 * rows, self._pf(wp), None,
@@ -442,8 +446,7 @@ class ConvNeXt:
                 keep = None if b["keep"] is None else b["keep"].data_ptr()
                 hip.check(lib.icamd_layerscale_bwd(dout, b["z2"].data_ptr(), self._pf(blk["gamma"]), keep, W(G[1]),
                                                    self._gf(blk["gamma"]), rows, dim, h * w, acc, csp, csb, s), "layer scale bwd")
-                gemm_bwd(blk["fc2"], b["a"].data_ptr(), G[1], N, h, w, G[2])                 # G2 = d a
-                hip.check(lib.icamd_gelu_bwd(G[2], b["z1"].data_ptr(), W(G[4]), b["z1"].numel(), s), "gelu bwd")   # G4 = d z1
+                gemm_bwd(blk["fc2"], b["a"].data_ptr(), G[1], N, h, w, G[4], gelu_z=b["z1"].data_ptr())   # G4 = d z1
                 gemm_bwd(blk["fc1"], b["h"].data_ptr(), G[4], N, h, w, G[1])                 # G1 = d h
                 ln_bwd(G[1], b["d"], b["st"], blk["nw"], blk["nb"], G[2], rows, dim)         # G2 = d (dwconv out)
                 bin_ptr, g2, hh, ww_, dd = b["in"].data_ptr(), G[2], h, w, dim

@@ -153,7 +153,7 @@ int icamd_conv2d_stats_rows(const icamd_conv_desc* d) {
 }
 
 static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
-                         const void* addend, float* stats, int relu, void* stream) {
+                         const void* addend, float* stats, int relu, void* stream, void* gelu_out = nullptr) {
   if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
   if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && stats == nullptr &&
@@ -161,13 +161,13 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.addend = (const bf16_t*)addend; g.bias = bias;
-    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin; g.relu = relu;
+    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin; g.relu = relu; g.gelu_out = (bf16_t*)gelu_out;
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
   }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w; p.out = (bf16_t*)y;
-  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats; p.relu = relu;
+  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats; p.relu = relu; p.gelu_out = (bf16_t*)gelu_out;
   p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin;
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
   p.P = d->OH; p.Q = d->OW; p.M = d->N * d->OH * d->OW;
@@ -195,6 +195,13 @@ int icamd_conv2d_fwd_act(const icamd_conv_desc* d, const void* x, const void* w,
   return conv_fwd_impl(d, x, w, y, bias, addend, nullptr, relu ? 1 : 0, stream);
 }
 
+int icamd_conv2d_fwd_gelu(const icamd_conv_desc* d, const void* x, const void* w, void* z, void* a, const float* bias,
+                          void* stream) {
+  ProfScope _prof(PC_IGEMM_FWD, stream);
+  if (a == nullptr) return ICAMD_ERR_BAD_ARG;
+  return conv_fwd_impl(d, x, w, z, bias, nullptr, nullptr, 0, stream, a);
+}
+
 int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta, const float* running_mean,
                           const float* running_var, float eps, int Cout, int K, void* w_folded, float* shift,
                           void* stream) {
@@ -207,7 +214,7 @@ int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta,
 }
 
 static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
-                      const uint8_t* addend_bits, const icamd_bn_bwd_fuse* f, void* stream) {
+                      const uint8_t* addend_bits, const icamd_bn_bwd_fuse* f, void* stream, const void* gelu_z = nullptr) {
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
   if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
@@ -217,7 +224,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.addend = (const bf16_t*)addend;
-    g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout;
+    g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout; g.gelu_z = (const bf16_t*)gelu_z;
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
   }
   float* partials = f ? f->partials : nullptr;
@@ -232,6 +239,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
       p.in = (const bf16_t*)dy; p.wt = (const bf16_t*)w_t; p.out = (bf16_t*)dx;
       p.addend = (const bf16_t*)addend;
       p.addend_bits = addend_bits;
+      p.gelu_z = (const bf16_t*)gelu_z;
       p.N = d->N; p.IH = d->OH; p.IW = d->OW; p.Cin = d->Cout;
       p.OH = d->IH; p.OW = d->IW; p.Cout = d->Cin;
       p.P = P; p.Q = Q; p.M = d->N * P * Q;
@@ -268,6 +276,13 @@ int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
   if (addend_maskbits != nullptr && (addend == nullptr || d == nullptr || d->Cin % 64 != 0)) return ICAMD_ERR_BAD_ARG;
   return dgrad_impl(d, dy, w_t, dx, addend, addend_maskbits, nullptr, stream);
+}
+
+int icamd_conv2d_dgrad_gelu(const icamd_conv_desc* d, const void* dy, const void* w_t, const void* z, void* dz,
+                            void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  if (z == nullptr) return ICAMD_ERR_BAD_ARG;
+  return dgrad_impl(d, dy, w_t, dz, nullptr, nullptr, nullptr, stream, z);
 }
 
 int icamd_conv2d_dgrad_stats_rows(const icamd_conv_desc* d) {

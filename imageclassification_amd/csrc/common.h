@@ -65,6 +65,26 @@ static inline FastDiv make_fastdiv(unsigned int d) {
   return f;
 }
 
+// exact (erf) GELU and its derivative, as torch.nn.GELU() / timm's Mlp use
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+}
+// 8 bf16 values at once: a = gelu(z);  dz = da * gelu'(z)
+__device__ __forceinline__ u32x4 gelu8(const u32x4 z) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(gelu_f(bf16_lo(z[e])), gelu_f(bf16_hi(z[e])));
+  return o;
+}
+__device__ __forceinline__ u32x4 gelu_bwd8(const u32x4 da, const u32x4 z) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    o[e] = pack_bf16x2(bf16_lo(da[e]) * gelu_grad_f(bf16_lo(z[e])), bf16_hi(da[e]) * gelu_grad_f(bf16_hi(z[e])));
+  return o;
+}
+
 static inline int icamd_launch_status() {
   return hipGetLastError() == hipSuccess ? ICAMD_OK : ICAMD_ERR_LAUNCH;
 }

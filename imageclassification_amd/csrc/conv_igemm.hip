@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
           s2[e] += gg[e] * ((yy[e] - bmu[e]) * bis[e]);
         }
       } else {
+        if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + roff[ps]));
         *(u32x4*)(p.out + roff[ps]) = o;
+        if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + roff[ps]) = gelu8(o);
         if (p.stats != nullptr) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -201,8 +201,13 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
   for (int ps = 0; ps < TM / RPP; ++ps) {
     const int ml = ps * RPP + rg;
     const int m = m0 + ml;
-    const u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ ml) & (CPR - 1)) << 4));
-    if (m < p.M && co < p.N) *(u32x4*)(p.out + (long long)m * p.N + co) = o;
+    u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ ml) & (CPR - 1)) << 4));
+    if (m < p.M && co < p.N) {
+      const long long off = (long long)m * p.N + co;
+      if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
+      *(u32x4*)(p.out + off) = o;
+      if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
+    }
   }
 }
 

@@ -20,6 +20,8 @@ struct IgemmParams {
   const float *bnb_mean, *bnb_invstd, *bnb_scale, *bnb_shift;
   int bnb_relu;
   int relu;              // EPI 0 only: clamp the sum at zero before rounding (inference epilogue)
+  bf16_t* gelu_out;      // EPI 0, optional second output laid out like out: gelu(rounded out)   (Mlp fc1 forward)
+  const bf16_t* gelu_z;  // EPI 0, optional, laid out like out: out = rounded result * gelu'(gelu_z)  (Mlp fc2 data gradient)
   int N, IH, IW, Cin;
   int OH, OW, Cout;
   int P, Q, M;           // output sub-grid and row count N*P*Q
@@ -43,6 +45,8 @@ struct GemmNtParams {
   const float* bias;     // optional [N]
   int M, N, K;
   int relu;              // clamp at zero before rounding
+  bf16_t* gelu_out;      // optional second output [M][N]: gelu(rounded out)
+  const bf16_t* gelu_z;  // optional [M][N]: out = rounded result * gelu'(gelu_z)
   int ntiles_n;          // filled by the launcher
 };
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream);

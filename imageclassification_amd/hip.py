@@ -41,6 +41,8 @@ def conv_desc(N, IH, IW, Cin, Cout, KH, KW, stride, pad):
 _P = c_void_p
 _SIGNATURES = {
     "icamd_abi_version": (c_int, []),
+    "icamd_conv2d_fwd_gelu": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "icamd_conv2d_dgrad_gelu": (c_int, [_P, _P, _P, _P, _P, _P]),
     "icamd_conv2d_fwd_act": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P]),
     "icamd_bn_fold_filters": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     "icamd_conv2d_stats_rows": (c_int, [POINTER(ConvDesc)]),

@@ -355,8 +355,9 @@ class VisionTransformer:
             hip.check(lib.icamd_layernorm_fwd(b["x1"].data_ptr(), self._pf(blk["n2w"]), self._pf(blk["n2b"]),
                                               b["h2"].data_ptr(), b["st2"].data_ptr(), b["st2"].data_ptr() + 4 * M, M, D, LN_EPS,
                                               s), "norm2")
-            self._linear(blk["fc1"], b["h2"], b["z"], M, None, s)
-            hip.check(lib.icamd_gelu_fwd(b["z"].data_ptr(), b["a"].data_ptr(), b["z"].numel(), s), "gelu")
+            l1 = blk["fc1"]                                                       # z = fc1(h2), a = gelu(z): one kernel
+            hip.check(lib.icamd_conv2d_fwd_gelu(ctypes.byref(l1.desc(M)), b["h2"].data_ptr(), self._w(l1), b["z"].data_ptr(),
+                                                b["a"].data_ptr(), self._pf(l1.b), s), l1.name + " + gelu")
             self._linear(blk["fc2"], b["a"], b["x2"], M, b["x1"], s)              # x2 = x1 + mlp
             x = b["x2"]
         ws["x_last"] = x
@@ -386,7 +387,7 @@ class VisionTransformer:
         lane = self._side_lane()
         lane.begin()
 
-        def lin_bwd(l, x, dy, rows, dx):
+        def lin_bwd(l, x, dy, rows, dx, gelu_z=None):
             """weight, bias gradients (+ data gradient into dx when given) of y = x W^T + b.  The weight gradient goes to
             the side lane (streams.py); `dy` is protected from being overwritten until it has been read."""
             d = l.desc(rows)
@@ -395,8 +396,12 @@ class VisionTransformer:
                                              l.name + " wgrad+bias"), reads=(dy.data_ptr(),))
             if dx is not None:
                 lane.before_write(dx.data_ptr())
-                hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), self._wt(l), dx.data_ptr(), None, None, s),
-                          l.name + " dgrad")
+                if gelu_z is None:
+                    hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d), dy.data_ptr(), self._wt(l), dx.data_ptr(), None, None, s),
+                              l.name + " dgrad")
+                else:   # dx = (dy W) * gelu'(z): the GELU backward rides in the data-gradient kernel's store pass
+                    hip.check(lib.icamd_conv2d_dgrad_gelu(ctypes.byref(d), dy.data_ptr(), self._wt(l), gelu_z.data_ptr(),
+                                                          dx.data_ptr(), s), l.name + " dgrad + gelu bwd")
 
         def ln_bwd(dy, x, st, wp, bp, addend, dx, rows):
             lane.before_write(dx.data_ptr())
@@ -415,10 +420,7 @@ class VisionTransformer:
         spare = [g1, g2]
         for blk, b in zip(reversed(self.blocks), reversed(ws["blocks"])):
             # dx = grad wrt x2
-            lin_bwd(blk["fc2"], b["a"], dx, M, ws["g3072"])                       # d a
-            lane.before_write(ws["g3072b"].data_ptr())
-            hip.check(lib.icamd_gelu_bwd(ws["g3072"].data_ptr(), b["z"].data_ptr(), ws["g3072b"].data_ptr(), b["z"].numel(), s),
-                      "gelu bwd")                                                 # d z
+            lin_bwd(blk["fc2"], b["a"], dx, M, ws["g3072b"], gelu_z=b["z"])       # d z = (dx W2) * gelu'(z)
             dh2 = spare[0]
             lin_bwd(blk["fc1"], b["h2"], ws["g3072b"], M, dh2)
             dx1 = spare[1]

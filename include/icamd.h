@@ -53,6 +53,10 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
  * icamd_bn_fold_filters): y = [relu](conv(x, w) + bias + addend), one rounding; no statistics. */
 int icamd_conv2d_fwd_act(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                          const void* addend, int relu, void* stream);
+/* Mlp fc1 forward with the activation fused into the store pass: z = conv(x, w) + bias rounded to bf16, a = gelu(z)
+ * (exact erf GELU of the ROUNDED z: bit-identical to icamd_conv2d_fwd followed by icamd_gelu_fwd, one read of z less). */
+int icamd_conv2d_fwd_gelu(const icamd_conv_desc* d, const void* x, const void* w, void* z, void* a, const float* bias,
+                          void* stream);
 /* Eval-mode BatchNorm (running statistics) folded into the [Cout][K] fp32 filters in front of it:
  * w_folded = bf16(w * gamma/sqrt(running_var+eps)) per output channel, shift = beta - running_mean * that scale. */
 int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta, const float* running_mean,
@@ -65,6 +69,12 @@ int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta,
  * "output gradient x ReLU mask" without that product ever being materialised. */
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
                        const uint8_t* addend_maskbits, void* stream);
+
+/* Mlp fc2 data gradient with the GELU backward fused into the store pass: dz = bf16(conv_transpose(dy, w)) * gelu'(z),
+ * z shaped like dz (bit-identical to icamd_conv2d_dgrad followed by icamd_gelu_bwd; the gradient of the GELU output is
+ * never written). */
+int icamd_conv2d_dgrad_gelu(const icamd_conv_desc* d, const void* dy, const void* w_t, const void* z, void* dz,
+                            void* stream);
 
 /* Data gradient with the NEXT BatchNorm backward's first pass fused into the epilogue: the tensor this call produces
  * is the output-gradient of a BatchNorm(+residual)+ReLU layer, so the kernel applies that layer's ReLU mask

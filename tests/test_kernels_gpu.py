@@ -248,6 +248,41 @@ def test_conv_fwd_act_and_bn_fold(lib, case):
         assert R.rel_l2(got, full) <= 1e-2
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 96, 384), (1, 20, 20, 192, 768), (4, 64, 64, 256, 1024)])
+def test_pointwise_gelu_epilogues(lib, case):
+    """fc1 forward with GELU in the store pass and fc2 data gradient with the GELU backward in the store pass are
+    bit-identical to the two-kernel sequences they replace (and those are oracle-checked elsewhere); both GEMM kernels
+    (128x128 implicit GEMM and the 256-row tile kernel, picked by size) are covered."""
+    hip = _hip()
+    N, H, W, Cin, Cout = case
+    d = hip.conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0)
+    x = to_dev_bf16(rnd_bf16(N, H, W, Cin, seed=41))
+    w = rnd_bf16(Cout, 1, 1, Cin, scale=(1.0 / Cin) ** 0.5, seed=42)
+    wd = to_dev_bf16(w)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(43)).to(DEV)
+    z1 = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    a1 = torch.empty_like(z1); z2 = torch.empty_like(z1); a2 = torch.empty_like(z1)
+    s = hip.stream_ptr()
+    assert lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(x), hip.ptr(wd), hip.ptr(z1), hip.ptr(bias), None, None, s) == 0
+    assert lib.icamd_gelu_fwd(hip.ptr(z1), hip.ptr(a1), z1.numel(), s) == 0
+    assert lib.icamd_conv2d_fwd_gelu(ctypes.byref(d), hip.ptr(x), hip.ptr(wd), hip.ptr(z2), hip.ptr(a2), hip.ptr(bias), s) == 0
+    sync()
+    assert torch.equal(z1, z2) and torch.equal(a1, a2)
+    ref_a = R.bf16_round(torch.nn.functional.gelu(z1.float().cpu()))
+    assert R.rel_l2(a2.float().cpu(), ref_a) <= 1e-3
+    # backward of the layer that consumes `a`: d z = (dy W) * gelu'(z), here with this layer's shapes transposed
+    dy = to_dev_bf16(rnd_bf16(N, H, W, Cout, seed=44))
+    zin = to_dev_bf16(rnd_bf16(N, H, W, Cin, seed=45))
+    w_t = to_dev_bf16(w.permute(3, 1, 2, 0).contiguous())
+    da = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+    dz1 = torch.empty_like(da); dz2 = torch.empty_like(da)
+    assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dy), hip.ptr(w_t), hip.ptr(da), None, None, s) == 0
+    assert lib.icamd_gelu_bwd(hip.ptr(da), hip.ptr(zin), hip.ptr(dz1), da.numel(), s) == 0
+    assert lib.icamd_conv2d_dgrad_gelu(ctypes.byref(d), hip.ptr(dy), hip.ptr(w_t), hip.ptr(zin), hip.ptr(dz2), s) == 0
+    sync()
+    assert torch.equal(dz1, dz2)
+
+
 WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0)]
 
 
