@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
 #define LPTR(p) ((void __attribute__((address_space(3)))*)(p))

@@ -3,10 +3,8 @@
 // backbone/convnext.py:21-56 (dwconv 7x7 pad 3 groups=dim -> LayerNorm -> Linear 4x -> GELU -> Linear -> gamma ->
 // drop_path -> residual); in the classification path the same block comes from timm's convnext_tiny (train.py:194).
 //
-// A depthwise conv is a 49-tap stencil per channel (no channel mixing): no MFMA, LDS-tiled.  A workgroup owns an
-// 8x8 output tile x 32 channels: the 14x14x32 input halo and the 49x32 filter taps are staged in LDS once, every
-// thread produces one 8-channel (16 B) output vector from 49 LDS reads.  NHWC bf16 in/out, fp32 accumulation,
-// filters stored tap-major [7][7][C] (bf16 shadow of the fp32 master).
+// A depthwise conv is a 49-tap stencil per channel (no channel mixing): no MFMA, LDS-tiled, VALU-bound.  NHWC bf16
+// in/out, fp32 accumulation, filters stored tap-major [7][7][C] (bf16 shadow of the fp32 master).
 #include "common.h"
 #include "icamd_internal.h"
 
@@ -18,62 +16,108 @@ constexpr int CG = 32;             // channels per workgroup (4 vectors of 8)
 
 // y[n,h,w,c] = bias[c] + sum_{r,s} x[n,h+r-3,w+s-3,c] * w[r][s][c]      (flip: taps mirrored = data gradient)
 //            (+ addend[n,h,w,c])
-__global__ __launch_bounds__(256) void dwconv7_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                      const float* __restrict__ bias, const bf16_t* __restrict__ addend,
-                                                      bf16_t* __restrict__ y, int N, int H, int W, int C, int flip) {
-  __shared__ __attribute__((aligned(16))) bf16_t sx[HS * HS][CG];
-  __shared__ __attribute__((aligned(16))) bf16_t sw[49][CG];
-  const int tiles_w = (W + TS - 1) / TS, tiles_h = (H + TS - 1) / TS;
+//
+// Register-window kernel.  A thread owns a strip of 7 horizontally adjacent outputs of one image row for one 8-channel
+// vector and keeps their 56 fp32 accumulators in registers; for each kernel row it walks the 13 input vectors under the
+// strip once (one 16 B LDS read and one bf16->fp32 unpack each) and feeds every vector to the up-to-7 outputs that see it
+// through a different tap, with the row's seven tap vectors (fp32 in LDS) held in registers.  Per output vector that is
+// 13 LDS reads and 13 unpacks per kernel row instead of 49 + 49 of each for the whole stencil done output-by-output, and
+// the multiply-adds are written on float2 so they issue as v_pk_fma_f32: the stencil is VALU-bound (98 flop per output
+// element, no MFMA shape), so instruction count is the roofline.
+// A workgroup covers TR rows x NS strips (TR * NS = 64) of the [N*H] x W plane for 32 channels; rows are GLOBAL rows
+// g = n*H + h, contiguous in NHWC memory across images, so small feature maps (14x14, 7x7) still fill the workgroup:
+// the halo is staged from contiguous global rows and each thread skips the kernel rows that would leave its own image.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void dwconv7_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, const bf16_t* __restrict__ addend,
+                                                         bf16_t* __restrict__ y, int N, int H, int W, int C, int flip) {
+  constexpr int TR = 64 / NS;            // global rows per workgroup
+  constexpr int HR = TR + 6;             // halo rows
+  constexpr int HC = 7 * NS + 6;         // halo columns
+  __shared__ __attribute__((aligned(16))) bf16_t sx[HR * HC][CG];
+  __shared__ __attribute__((aligned(16))) float sw[49][CG];
+  const int tiles_w = (W + 7 * NS - 1) / (7 * NS);
+  const long long rows_total = (long long)N * H;
   int b = blockIdx.x;
   const int cgi = b % (C / CG); b /= (C / CG);
-  const int tw = b % tiles_w; b /= tiles_w;
-  const int th = b % tiles_h;
-  const int n = b / tiles_h;
-  const int c0 = cgi * CG, h0 = th * TS, w0 = tw * TS;
+  const int tw = b % tiles_w;
+  const long long g0 = (long long)(b / tiles_w) * TR;
+  const int c0 = cgi * CG, w0 = tw * 7 * NS;
   const int tid = threadIdx.x;
-  for (int i = tid; i < HS * HS * 4; i += 256) {
+  for (int i = tid; i < HR * HC * 4; i += 256) {
     const int v = i & 3, pix = i >> 2;
-    const int hh = h0 - 3 + pix / HS, ww = w0 - 3 + pix % HS;
+    const int hr = pix / HC, hc = pix - hr * HC;
+    const long long g = g0 - 3 + hr;
+    const int ww = w0 - 3 + hc;
     u32x4 val = {0u, 0u, 0u, 0u};
-    if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
-      val = *(const u32x4*)(x + (((long long)n * H + hh) * W + ww) * C + c0 + v * 8);
+    if (g >= 0 && g < rows_total && (unsigned)ww < (unsigned)W) val = *(const u32x4*)(x + (g * W + ww) * C + c0 + v * 8);
     *(u32x4*)&sx[pix][v * 8] = val;
   }
-  for (int i = tid; i < 49 * 4; i += 256) {
-    const int v = i & 3, t = i >> 2;
-    const int ts = flip ? 48 - t : t;
-    *(u32x4*)&sw[t][v * 8] = *(const u32x4*)(w + (long long)ts * C + c0 + v * 8);
+  for (int i = tid; i < 49 * CG; i += 256) {
+    const int t = i / CG, c = i - t * CG;
+    sw[t][c] = bf16_to_f32(w[(long long)(flip ? 48 - t : t) * C + c0 + c]);
   }
   __syncthreads();
-  const int v = tid & 3, p = tid >> 2;
-  const int ph = p / TS, pw = p % TS;
-  const int oh = h0 + ph, ow = w0 + pw;
-  float acc[8];
+  const int v = tid & 3, strip = (tid >> 2) % NS, lr = (tid >> 2) / NS;
+  const long long g = g0 + lr;
+  const int h = (int)(g % H);
+  f32x2 acc[7][4];
+  {
+    f32x2 b2[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = (bias != nullptr) ? bias[c0 + v * 8 + e] : 0.f;
+    for (int e = 0; e < 4; ++e)
+      b2[e] = (bias != nullptr) ? f32x2{bias[c0 + v * 8 + 2 * e], bias[c0 + v * 8 + 2 * e + 1]} : f32x2{0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 7; ++r)
+    for (int o = 0; o < 7; ++o)
 #pragma unroll
-    for (int s = 0; s < 7; ++s) {
-      const u32x4 xv = *(const u32x4*)&sx[(ph + r) * HS + pw + s][v * 8];
-      const u32x4 wv = *(const u32x4*)&sw[r * 7 + s][v * 8];
+      for (int e = 0; e < 4; ++e) acc[o][e] = b2[e];
+  }
+#pragma unroll 1
+  for (int r = 0; r < 7; ++r) {
+    if ((unsigned)(h + r - 3) >= (unsigned)H) continue;   // that input row belongs to another image (or to none)
+    f32x2 wv[7][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[2 * e] = fmaf(bf16_lo(xv[e]), bf16_lo(wv[e]), acc[2 * e]);
-        acc[2 * e + 1] = fmaf(bf16_hi(xv[e]), bf16_hi(wv[e]), acc[2 * e + 1]);
+    for (int t = 0; t < 7; ++t) {
+      const f32x4 lo = *(const f32x4*)&sw[r * 7 + t][v * 8], hi = *(const f32x4*)&sw[r * 7 + t][v * 8 + 4];
+      wv[t][0] = f32x2{lo[0], lo[1]}; wv[t][1] = f32x2{lo[2], lo[3]};
+      wv[t][2] = f32x2{hi[0], hi[1]}; wv[t][3] = f32x2{hi[2], hi[3]};
+    }
+    const bf16_t* row = &sx[(lr + r) * HC + strip * 7][v * 8];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const u32x4 xv = *(const u32x4*)(row + j * CG);
+      f32x2 xu[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xu[e] = f32x2{bf16_lo(xv[e]), bf16_hi(xv[e])};
+#pragma unroll
+      for (int o = 0; o < 7; ++o) {
+        if (j - o >= 0 && j - o < 7) {   // compile-time: output o sees input j through tap s = j - o
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[o][e] = __builtin_elementwise_fma(xu[e], wv[j - o][e], acc[o][e]);
+        }
       }
     }
-  if (oh < H && ow < W) {
-    const long long off = (((long long)n * H + oh) * W + ow) * C + c0 + v * 8;
-    if (addend != nullptr) {
-      const u32x4 a = *(const u32x4*)(addend + off);
+  }
+  if (g < rows_total) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[2 * e] += bf16_lo(a[e]); acc[2 * e + 1] += bf16_hi(a[e]); }
+    for (int o = 0; o < 7; ++o) {
+      const int ow = w0 + strip * 7 + o;
+      if (ow < W) {
+        const long long off = (g * W + ow) * C + c0 + v * 8;
+        f32x2 r2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r2[e] = acc[o][e];
+        if (addend != nullptr) {
+          const u32x4 a = *(const u32x4*)(addend + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { r2[e][0] += bf16_lo(a[e]); r2[e][1] += bf16_hi(a[e]); }
+        }
+        u32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(r2[e][0], r2[e][1]);
+        *(u32x4*)(y + off) = ov;
+      }
     }
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
-    *(u32x4*)(y + off) = o;
   }
 }
 
@@ -221,9 +265,16 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const bf16_t* __res
 int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* addend, bf16_t* y, int N, int H,
                          int W, int C, int flip, hipStream_t s) {
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
-  const long long blocks = (long long)N * ((H + TS - 1) / TS) * ((W + TS - 1) / TS) * (C / CG);
+  // strips of 7 outputs per row and workgroup: as many as the row needs, up to 8 (TR = 64 / NS global rows each)
+  const int ns = W <= 7 ? 1 : (W <= 14 ? 2 : (W <= 28 ? 4 : 8));
+  const long long rows = (long long)N * H;
+  const long long blocks = ((rows + 64 / ns - 1) / (64 / ns)) * ((W + 7 * ns - 1) / (7 * ns)) * (C / CG);
   if (blocks <= 0 || blocks >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
-  hipLaunchKernelGGL(dwconv7_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, addend, y, N, H, W, C, flip);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (ns == 1) hipLaunchKernelGGL(dwconv7_kernel<1>, grid, block, 0, s, x, w, bias, addend, y, N, H, W, C, flip);
+  else if (ns == 2) hipLaunchKernelGGL(dwconv7_kernel<2>, grid, block, 0, s, x, w, bias, addend, y, N, H, W, C, flip);
+  else if (ns == 4) hipLaunchKernelGGL(dwconv7_kernel<4>, grid, block, 0, s, x, w, bias, addend, y, N, H, W, C, flip);
+  else hipLaunchKernelGGL(dwconv7_kernel<8>, grid, block, 0, s, x, w, bias, addend, y, N, H, W, C, flip);
   return icamd_launch_status();
 }
 

@@ -860,7 +860,8 @@ def test_attention_fwd_bwd(lib, B, T, H):
         assert R.rel_l2(gd[:, sl], rd[:, sl]) <= 6e-3, name      # P, dS pass through bf16 MFMA operands
 
 
-@pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96)])
+@pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96), (3, 28, 28, 64),
+                                   (2, 11, 30, 32), (70, 3, 5, 32)])
 def test_dwconv7_fwd_dgrad_wgrad(lib, shape):
     hip = _hip()
     N, H, W, C = shape
