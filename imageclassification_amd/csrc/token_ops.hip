@@ -1,7 +1,7 @@
 // Token-wise kernels for the transformer / ConvNeXt branches of the step (gfx950): LayerNorm forward / backward over
 // the channel dimension of [rows][C] bf16 tensors, exact (erf) GELU forward / backward, and a two-level column sum
-// (bias gradients).  One wavefront per row for LayerNorm: 8 B per lane per 256-channel slice, statistics by
-// wave shuffles in fp32 (two-pass variance, as torch.nn.functional.layer_norm), fp32 mean / rstd saved for backward.
+// (bias gradients).  LayerNorm: 16 / 32 / 64 lanes per row by channel count, 16 B per lane, statistics by xor-shuffles
+// in fp32 (two-pass variance, as torch.nn.functional.layer_norm), fp32 mean / rstd saved for backward.
 // Replaces what ATen runs for timm's LayerNorm / GELU / Linear-bias layers under `model(samples)` and
 // `loss.backward()` (/root/reference/engine.py:48,51,64,72; ConvNeXt block spec
 // /root/reference/semantic_segmentation/backbone/convnext.py:43-56,158-182).
@@ -10,145 +10,171 @@
 
 namespace {
 
-constexpr int LN_MAX_IT = 4;   // C <= 1024
+constexpr int LN_MAX_C = 1024;   // two 16 B vectors per lane at 64 lanes per row
 
-__device__ __forceinline__ void unpack4(u32x2 v, float* f) {
-  f[0] = bf16_lo(v[0]); f[1] = bf16_hi(v[0]); f[2] = bf16_lo(v[1]); f[3] = bf16_hi(v[1]);
+// LayerNorm rows are short (96 ... 768 channels): a whole wave per row leaves most lanes idle for ConvNeXt's 96 / 192
+// channels.  LPR lanes (16, 32 or 64) share a row, 64 / LPR rows are in flight per wave, each lane holds up to two
+// 8-channel vectors (16 B loads), statistics are reduced by xor-shuffles inside the lane group.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float cross_group_sum(float v) {   // same lane position of every group in the wave
+#pragma unroll
+  for (int m = LPR; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
 }
 
-// y = (x - mean) * rstd * gamma + beta ; grid = ceil(rows / 4), block 256 (one wave per row)
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(v[e]); f[2 * e + 1] = bf16_hi(v[e]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+  return o;
+}
+
+// y = (x - mean) * rstd * gamma + beta (two-pass variance in registers, as torch.nn.functional.layer_norm)
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             long long rows, int C, float eps) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bf16_t* xr = x + row * C;
-  float v[LN_MAX_IT][4];
-  const int nit = (C + 255) / 256;
-  float s = 0.f;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int nvec = C >> 3;
+  const bool has[2] = {sub < nvec, sub + LPR < nvec};
+  float g[2][8], bt[2][8];
 #pragma unroll
-  for (int it = 0; it < LN_MAX_IT; ++it) {
-    if (it < nit) {
-      const int c = it * 256 + lane * 4;
-      if (c < C) { unpack4(*(const u32x2*)(xr + c), v[it]); s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]); }
-      else { v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f; }
-    }
+  for (int it = 0; it < 2; ++it) {
+    const int c = (has[it] ? sub + it * LPR : 0) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g[it][e] = gamma[c + e]; bt[it][e] = beta[c + e]; }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  const float invC = 1.f / (float)C;
+  const long long stride = (long long)gridDim.x * 4 * RPW;
+  for (long long rbase = ((long long)blockIdx.x * 4 + wave) * RPW; rbase < rows; rbase += stride) {
+    const long long row = rbase + grp;
+    const bool live = row < rows;
+    const bf16_t* xr = x + (live ? row : 0) * C;
+    float v[2][8];
+    float s = 0.f;
 #pragma unroll
-  for (int it = 0; it < LN_MAX_IT; ++it) {
-    if (it < nit) {
-      const int c = it * 256 + lane * 4;
-      if (c < C) {
+    for (int it = 0; it < 2; ++it) {
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (has[it] && live) raw = *(const u32x4*)(xr + (sub + it * LPR) * 8);
+      unpack8(raw, v[it]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v[it][e] - mean; q += d * d; }
-      }
+      for (int e = 0; e < 8; ++e) s += v[it][e];
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-  bf16_t* yr = y + row * C;
+    const float mean = group_sum<LPR>(s) * invC;
+    float q = 0.f;
 #pragma unroll
-  for (int it = 0; it < LN_MAX_IT; ++it) {
-    if (it < nit) {
-      const int c = it * 256 + lane * 4;
-      if (c < C) {
-        const f32x4 g = *(const f32x4*)(gamma + c);
-        const f32x4 b = *(const f32x4*)(beta + c);
-        float o[4];
+    for (int it = 0; it < 2; ++it)
+      if (has[it]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd * g[e] + b[e];
-        u32x2 pk;
-        pk[0] = pack_bf16x2(o[0], o[1]);
-        pk[1] = pack_bf16x2(o[2], o[3]);
-        *(u32x2*)(yr + c) = pk;
+        for (int e = 0; e < 8; ++e) { const float d = v[it][e] - mean; q += d * d; }
       }
-    }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * invC + eps);
+    if (!live) continue;
+    if (sub == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    bf16_t* yr = y + row * C;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      if (has[it]) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[it][e] - mean) * rstd * g[it][e] + bt[it][e];
+        *(u32x4*)(yr + (sub + it * LPR) * 8) = pack8(o);
+      }
   }
 }
 
-// dx = rstd * (dy*gamma - mean_C(dy*gamma) - xhat * mean_C(dy*gamma*xhat)); per-workgroup partial column sums of
-// dy (-> dbeta) and dy*xhat (-> dgamma) in part[blk][2][C].  Each wave walks `rows_per_wave` rows.
+// dx = rstd * (dy*gamma - mean_C(dy*gamma) - xhat * mean_C(dy*gamma*xhat)) (+ addend); per-workgroup partial column
+// sums of dy (-> dbeta) and dy*xhat (-> dgamma) in part[blk][2][C].  Each wave walks `rows_per_wave` rows, 64/LPR at a time.
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const bf16_t* __restrict__ addend,
                                                             bf16_t* __restrict__ dx, float* __restrict__ part, long long rows,
                                                             int C, int rows_per_wave) {
-  __shared__ float red[4][2][LN_MAX_IT * 256];
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[4][2][LN_MAX_C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nit = (C + 255) / 256;
-  float sb[LN_MAX_IT][4], sg[LN_MAX_IT][4];
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int nvec = C >> 3;
+  const bool has[2] = {sub < nvec, sub + LPR < nvec};
+  float g[2][8], sb[2][8], sg[2][8];
 #pragma unroll
-  for (int it = 0; it < LN_MAX_IT; ++it)
+  for (int it = 0; it < 2; ++it) {
+    const int c = (has[it] ? sub + it * LPR : 0) * 8;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { sb[it][e] = 0.f; sg[it][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { g[it][e] = gamma[c + e]; sb[it][e] = 0.f; sg[it][e] = 0.f; }
+  }
+  const float invC = 1.f / (float)C;
   const long long r0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
   const long long r1 = (rows < r0 + rows_per_wave) ? rows : r0 + rows_per_wave;
-  for (long long row = r0; row < r1; ++row) {
-    const float mu = mean[row], rs = rstd[row];
-    float dyg[LN_MAX_IT][4], xh[LN_MAX_IT][4];
+  for (long long rbase = r0; rbase < r1; rbase += RPW) {
+    const long long row = rbase + grp;
+    const bool live = row < r1;
+    const long long ro = (live ? row : 0) * C;
+    const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+    float dyg[2][8], xh[2][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
-      if (it < nit) {
-        const int c = it * 256 + lane * 4;
-        if (c < C) {
-          float d[4], xv[4];
-          unpack4(*(const u32x2*)(dy + row * C + c), d);
-          unpack4(*(const u32x2*)(x + row * C + c), xv);
-          const f32x4 g = *(const f32x4*)(gamma + c);
+    for (int it = 0; it < 2; ++it) {
+      u32x4 rd = {0u, 0u, 0u, 0u}, rx = {0u, 0u, 0u, 0u};
+      if (has[it] && live) {
+        rd = *(const u32x4*)(dy + ro + (sub + it * LPR) * 8);
+        rx = *(const u32x4*)(x + ro + (sub + it * LPR) * 8);
+      }
+      float d[8], xv[8];
+      unpack8(rd, d);
+      unpack8(rx, xv);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xh[it][e] = (xv[e] - mu) * rs;
-            dyg[it][e] = d[e] * g[e];
-            s1 += dyg[it][e];
-            s2 += dyg[it][e] * xh[it][e];
-            sb[it][e] += d[e];
-            sg[it][e] += d[e] * xh[it][e];
-          }
-        } else {
+      for (int e = 0; e < 8; ++e) {
+        xh[it][e] = (has[it] && live) ? (xv[e] - mu) * rs : 0.f;
+        dyg[it][e] = d[e] * g[it][e];
+        s1 += dyg[it][e];
+        s2 += dyg[it][e] * xh[it][e];
+        sb[it][e] += d[e];
+        sg[it][e] += d[e] * xh[it][e];
+      }
+    }
+    const float c1 = group_sum<LPR>(s1) * invC, c2 = group_sum<LPR>(s2) * invC;
+    if (!live) continue;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { xh[it][e] = 0.f; dyg[it][e] = 0.f; }
+    for (int it = 0; it < 2; ++it)
+      if (has[it]) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (dyg[it][e] - c1 - xh[it][e] * c2);
+        if (addend != nullptr) {   // residual branch: the skip connection's gradient joins here
+          float a8[8];
+          unpack8(*(const u32x4*)(addend + ro + (sub + it * LPR) * 8), a8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += a8[e];
         }
+        *(u32x4*)(dx + ro + (sub + it * LPR) * 8) = pack8(o);
       }
-    }
-    const float c1 = wave_sum(s1) / (float)C, c2 = wave_sum(s2) / (float)C;
-#pragma unroll
-    for (int it = 0; it < LN_MAX_IT; ++it) {
-      if (it < nit) {
-        const int c = it * 256 + lane * 4;
-        if (c < C) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = rs * (dyg[it][e] - c1 - xh[it][e] * c2);
-          if (addend != nullptr) {   // residual branch: the skip connection's gradient joins here
-            float a4[4];
-            unpack4(*(const u32x2*)(addend + row * C + c), a4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += a4[e];
-          }
-          u32x2 pk;
-          pk[0] = pack_bf16x2(o[0], o[1]);
-          pk[1] = pack_bf16x2(o[2], o[3]);
-          *(u32x2*)(dx + row * C + c) = pk;
-        }
-      }
-    }
   }
-  // fold the 4 waves' column sums in wave order, one partial row per workgroup
+  // fold: lane groups of the wave (fixed xor order), then the 4 waves in wave order; one partial row per workgroup
 #pragma unroll
-  for (int it = 0; it < LN_MAX_IT; ++it) {
-    if (it < nit) {
+  for (int it = 0; it < 2; ++it)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        red[wave][0][it * 256 + lane * 4 + e] = sb[it][e];
-        red[wave][1][it * 256 + lane * 4 + e] = sg[it][e];
+    for (int e = 0; e < 8; ++e) {
+      const float b = cross_group_sum<LPR>(sb[it][e]), gg = cross_group_sum<LPR>(sg[it][e]);
+      if (grp == 0 && has[it]) {
+        red[wave][0][(sub + it * LPR) * 8 + e] = b;
+        red[wave][1][(sub + it * LPR) * 8 + e] = gg;
       }
     }
-  }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int which = i / C, c = i - which * C;
@@ -156,7 +182,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     part[((long long)blockIdx.x * 2 + which) * C + c] = s;
   }
 }
-
 
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ a, long long nvec) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -289,11 +314,19 @@ inline unsigned int ew_grid(long long nvec) {
 
 }  // namespace
 
+static inline int ln_lanes_per_row(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
+
 int icamd_layernorm_fwd_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                                long long rows, int C, float eps, hipStream_t s) {
-  if (C % 4 != 0 || C > LN_MAX_IT * 256) return ICAMD_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd,
-                     rows, C, eps);
+  if (C % 8 != 0 || C > LN_MAX_C || C <= 0) return ICAMD_ERR_UNSUPPORTED;
+  const int lpr = ln_lanes_per_row(C);
+  long long blocks = (rows + 4 * (64 / lpr) - 1) / (4 * (64 / lpr));
+  if (blocks > 2048) blocks = 2048;   // grid-stride beyond: 8 workgroups per CU keep enough loads in flight
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks), block(256);
+  if (lpr == 16) hipLaunchKernelGGL(layernorm_fwd_kernel<16>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  else if (lpr == 32) hipLaunchKernelGGL(layernorm_fwd_kernel<32>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<64>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
   return icamd_launch_status();
 }
 
@@ -305,11 +338,17 @@ int icamd_layernorm_bwd_blocks(long long rows) {
 
 int icamd_layernorm_bwd_launch(const bf16_t* dy, const bf16_t* x, const float* mean, const float* rstd, const float* gamma,
                                const bf16_t* addend, bf16_t* dx, float* part, long long rows, int C, hipStream_t s) {
-  if (C % 4 != 0 || C > LN_MAX_IT * 256) return ICAMD_ERR_UNSUPPORTED;
+  if (C % 8 != 0 || C > LN_MAX_C || C <= 0) return ICAMD_ERR_UNSUPPORTED;
   const int nblk = icamd_layernorm_bwd_blocks(rows);
   const int rpw = (int)((rows + (long long)nblk * 4 - 1) / ((long long)nblk * 4));
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dy, x, mean, rstd, gamma, addend, dx, part,
-                     rows, C, rpw);
+  const int lpr = ln_lanes_per_row(C);
+  const dim3 grid((unsigned)nblk), block(256);
+  if (lpr == 16)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw);
+  else if (lpr == 32)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<64>, grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw);
   return icamd_launch_status();
 }
 
