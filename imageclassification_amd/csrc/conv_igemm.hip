@@ -31,7 +31,7 @@ constexpr int BK = 64;
 // EPI 0: out = [relu](acc (+bias)(+addend)); optional statistics of the rounded outputs (BatchNorm forward).
 // EPI 1: data-gradient with the next BatchNorm-backward fused in: g = (acc + addend) * [ReLU mask], out = g, and the
 //        partial rows hold sum(g) and sum(g * xhat), xhat from the BN input `bnb_y` (BatchNorm backward, pass 1).
-template <int BN, bool CIN8, int EPI>
+template <int BN, int KMODE, int EPI>   // KMODE 0: uniform taps; 1: per-chunk taps; 2: single tap with a partial last k-step
 __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) : 2)) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int NSTAGE = ICAMD_IGEMM_STAGES;
   constexpr int A_BYTES = BM * BK * 2;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
   auto stage = [&](int ks, int buf) {
     unsigned char* sA = smem + buf * STAGE_BYTES;
     unsigned char* sB = sA + A_BYTES;
-    if constexpr (!CIN8) {
-      // all 64 k of this step share one tap (Cin % 64 == 0): tap index and channel offset are wave-uniform
+    if constexpr (KMODE != 1) {
+      // all 64 k of this step share one tap (Cin % 64 == 0, or a single tap): tap index and channel offset are wave-uniform
       const int kk0 = ks * BK;
       const int t = kk0 / p.Cin;          // uniform
       const int ci0 = kk0 - t * p.Cin;
@@ -109,13 +109,21 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-        const bool ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
+        // kk0 + chunk < Ktot only matters for single-tap problems whose channel count is not a multiple of 64 (ConvNeXt's
+        // 96-channel pointwise layers): the last k-step is then partly past the end of the row and reads zeros
+        const bool ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW) &&
+                        (KMODE != 2 || kk0 + a_lc[j] < p.Ktot);
         const bf16_t* src = ok ? in + (a_base[j] + tapoff + a_lc[j]) : zero;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * 32 + j * 8) * 128), 16, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < BROWS; ++j) {
-        const bf16_t* src = (b_off[j] >= 0) ? wt + (b_off[j] + woff) : zero;
+        bool bok = b_off[j] >= 0;
+        if constexpr (KMODE == 2) {
+          const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
+          bok = bok && (kk0 + ((lane & 7) ^ ((row >> 1) & 7)) * 8 < p.Ktot);
+        }
+        const bf16_t* src = bok ? wt + (b_off[j] + woff) : zero;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
       }
     } else {
@@ -387,11 +395,11 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
   }
 }
 
-template <int BN, bool CIN8, int EPI>
+template <int BN, int KMODE, int EPI>   // KMODE 0: uniform taps; 1: per-chunk taps; 2: single tap with a partial last k-step
 int launch(const IgemmParams& p, hipStream_t stream) {
   const int ntm = (p.M + BM - 1) / BM;
   dim3 grid((unsigned)(ntm * p.ntiles_n));
-  hipLaunchKernelGGL((conv_igemm_kernel<BN, CIN8, EPI>), grid, dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BN, KMODE, EPI>), grid, dim3(256), 0, stream, p);
   return icamd_launch_status();
 }
 
@@ -401,7 +409,9 @@ int icamd_igemm_pick_bn(int Cout) { return Cout <= 64 ? 64 : 128; }
 
 int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   if (p.Cout % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
-  const bool cin8 = (p.Cin % 64 != 0);   // "general" path: per-chunk taps (the 8-channel stem, ConvNeXt's 96, ...)
+  // "general" path: per-chunk taps (the 8-channel stem, ConvNeXt's 2x2 downsample at 96 channels, ...).  Single-tap
+  // problems stay on the uniform-tap path whatever their channel count: a k-step cannot straddle taps there.
+  const bool cin8 = (p.Cin % 64 != 0) && p.ntaps != 1;
   if (p.Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if (cin8 && !p.regular_taps) return ICAMD_ERR_UNSUPPORTED;   // strided data gradients need Cout % 64 == 0
   if (cin8 && p.Ktot != p.ntaps * p.Cin) return ICAMD_ERR_BAD_ARG;
@@ -420,8 +430,10 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   if (p.bnb_y != nullptr) {
     if (cin8 || p.stats == nullptr || p.bnb_mean == nullptr || p.bnb_invstd == nullptr) return ICAMD_ERR_BAD_ARG;
     if (p.bnb_relu && p.bnb_mask == nullptr && (p.bnb_scale == nullptr || p.bnb_shift == nullptr)) return ICAMD_ERR_BAD_ARG;
-    return bn == 64 ? launch<64, false, 1>(p, stream) : launch<128, false, 1>(p, stream);
+    if (p.Cin % 64 != 0) return ICAMD_ERR_UNSUPPORTED;
+    return bn == 64 ? launch<64, 0, 1>(p, stream) : launch<128, 0, 1>(p, stream);
   }
-  if (bn == 64) return cin8 ? launch<64, true, 0>(p, stream) : launch<64, false, 0>(p, stream);
-  return cin8 ? launch<128, true, 0>(p, stream) : launch<128, false, 0>(p, stream);
+  const bool tail = !cin8 && (p.Cin % 64 != 0);   // single tap, channel count not a multiple of the k-step
+  if (bn == 64) return cin8 ? launch<64, 1, 0>(p, stream) : (tail ? launch<64, 2, 0>(p, stream) : launch<64, 0, 0>(p, stream));
+  return cin8 ? launch<128, 1, 0>(p, stream) : (tail ? launch<128, 2, 0>(p, stream) : launch<128, 0, 0>(p, stream));
 }

@@ -291,9 +291,8 @@ int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, f
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
   const int nb = icamd_dwconv7_wgrad_blocks(N, H, W, C);
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((unsigned)(nb * (C / CG))), dim3(256), 0, s, x, dy, part, N, H, W, C, nb);
-  const long long n = 49ll * C;
-  hipLaunchKernelGGL(rows_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nb, n, dw, accumulate);
-  return icamd_launch_status();
+  // fold the nb partial rows with the slab reducer (many workgroups, fixed order) -- 49*C is a multiple of 4
+  return icamd_slab_reduce_launch(part, dw, 49ll * C, nb, accumulate, s);
 }
 
 static unsigned int ls_grid(long long nvec) {

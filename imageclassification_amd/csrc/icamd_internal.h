@@ -69,3 +69,5 @@ struct WgradParams {
 };
 int icamd_wgrad_launch(WgradParams& p, hipStream_t stream);
 void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split);
+// out[i] = (accumulate ? out[i] : 0) + sum over S slabs of slab[s][i], fixed order; n % 4 == 0
+int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream);
