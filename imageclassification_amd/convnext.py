@@ -407,6 +407,7 @@ class ConvNeXt:
         G = [g.data_ptr() for g in self._scratch(ws)]
 
         lane = self._side_lane()
+        lane.enabled = lane.side is not None and getattr(self, "wgrad_side_stream", True)
         lane.begin()
 
         def W(ptr):

@@ -100,6 +100,7 @@ class ResNet:
         self.num_batches_tracked = 0
         self._ws = {}
         self._streams_ready = False
+        self.wgrad_side_stream = True   # bench.py turns this off for its per-kernel timing pass
         self.grad_ready_hook = None   # called with (param_offset_lo, param_offset_hi) as gradients complete
         self.init_weights(zero_init_last=zero_init_last, seed=seed)
 
@@ -621,7 +622,7 @@ class ResNet:
         D0, D1, T, DA = (b.data_ptr() for b in bufs[:4])
         ypool = [b.data_ptr() for b in bufs[4:]]
         hook = self.grad_ready_hook
-        side = self._wgrad_stream() if _WGRAD_STREAM else None
+        side = self._wgrad_stream() if (_WGRAD_STREAM and self.wgrad_side_stream) else None
         ws_side = side.cuda_stream if side is not None else s
         pending = [None] * len(ypool)     # per pool buffer: event of the last side-stream wgrad reading it
         state = {"next": 0, "last": None}

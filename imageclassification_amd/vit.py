@@ -385,6 +385,7 @@ class VisionTransformer:
         scale = 64 ** -0.5
 
         lane = self._side_lane()
+        lane.enabled = lane.side is not None and getattr(self, "wgrad_side_stream", True)
         lane.begin()
 
         def lin_bwd(l, x, dy, rows, dx, gelu_z=None):
