@@ -147,13 +147,24 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
     s_last = last;
   }
   __syncthreads();
-  if (!s_last || threadIdx.x >= 64 || c >= C) return;
+  if (!s_last) return;
+  // the last arriver folds the chunk rows with all 16 row lanes (chunk k on lane k % 16, lanes then summed in lane order:
+  // a fixed order, and 4 dependent loads per lane instead of 64 on one wave)
   const int nchunks = gridDim.y;
-  double t1 = 0.0, t2 = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
-    t1 += chunks[((long long)k * 2 + 0) * C + c];
-    t2 += chunks[((long long)k * 2 + 1) * C + c];
+  double p1 = 0.0, p2 = 0.0;
+  if (c < C) {
+    for (int k = rl; k < nchunks; k += 16) {
+      p1 += chunks[((long long)k * 2 + 0) * C + c];
+      p2 += chunks[((long long)k * 2 + 1) * C + c];
+    }
   }
+  red[rl][0][cc] = p1;
+  red[rl][1][cc] = p2;
+  __syncthreads();
+  if (threadIdx.x >= 64 || c >= C) return;
+  double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { t1 += red[j][0][cc]; t2 += red[j][1][cc]; }
   if constexpr (MODE == 0) {
     const double mean = t1 / a.count;
     double var = t2 / a.count - mean * mean;
