@@ -64,25 +64,37 @@ def vit_flops_per_image(net):
                    (f"blocks.{i}.fc1", 2 * T * D * Hd), (f"blocks.{i}.fc2", 2 * T * Hd * D),
                    (f"blocks.{i}.attention", 4 * net.heads * T * T * 64)]
     layers.append(("head", 2 * D * net.num_classes))
+    # algorithmic bytes per GEMM (bf16 input rows + output rows, filter elements); attention: qkv in, out
+    lb = [(2 * 224 * 224 * 8, 2 * (T - 1) * D, D * 8 * net.patch * net.patch)]
+    for _ in range(net.depth):
+        lb += [(2 * T * D, 2 * T * 3 * D, 3 * D * D), (2 * T * D, 2 * T * D, D * D), (2 * T * D, 2 * T * Hd, D * Hd),
+               (2 * T * Hd, 2 * T * D, D * Hd), (2 * T * 3 * D, 2 * T * D, 0)]
+    lb.append((2 * D, 2 * net.num_classes, D * net.num_classes))
+    conv_flops_per_image.layer_bytes = lb
     return layers
 
 
 def convnext_flops_per_image(net, hw):
     """Algorithmic forward FLOPs of the GEMM-shaped layers (stem, downsample, pointwise MLPs, head); the depthwise
     stencils (2*49 flop per output element) are listed separately as `dwconv`."""
-    layers, dw = [], 0
+    layers, dw, lb = [], 0, []
     h = w = hw // 4
     layers.append(("stem", 2 * h * w * net.dims[0] * 3 * 16))
+    lb.append((2 * hw * hw * 8, 2 * h * w * net.dims[0], net.dims[0] * 8 * 16))
     for si, st in enumerate(net.stages):
         dim = st["dim"]
         if si > 0:
+            lb.append((2 * h * w * net.dims[si - 1], 2 * (h // 2) * (w // 2) * dim, dim * net.dims[si - 1] * 4))
             h, w = h // 2, w // 2
             layers.append((f"stages.{si}.downsample", 2 * h * w * dim * net.dims[si - 1] * 4))
         for blk in st["blocks"]:
             layers.append((blk["name"] + ".mlp", 2 * 2 * h * w * dim * 4 * dim))
+            lb += [(2 * h * w * dim, 2 * h * w * 4 * dim, 4 * dim * dim), (2 * h * w * 4 * dim, 2 * h * w * dim, 4 * dim * dim)]
             dw += 2 * 49 * h * w * dim
     layers.append(("head", 2 * net.dims[-1] * net.num_classes))
+    lb.append((2 * net.dims[-1], 2 * net.num_classes, net.dims[-1] * net.num_classes))
     layers.append(("dwconv", dw))
+    conv_flops_per_image.layer_bytes = lb   # algorithmic bytes of the GEMM-shaped layers (input, output, filter elements)
     return layers
 
 
@@ -229,7 +241,9 @@ def main():
                                                            else conv_flops_per_image(net, HW))
         fwd_flops = sum(f for _, f in layers) * B           # per step, all conv/FC (and attention) forward launches
         stem_flops = layers[0][1] * B
-        algo = {"conv_fwd": fwd_flops, "conv_dgrad": fwd_flops - stem_flops, "conv_wgrad": fwd_flops}
+        # the mixup recipe runs the reference's second (train-accuracy) forward: two forward passes per step
+        nfwd = 2 if (args.mixup and os.environ.get("ICAMD_CHEAP_MIXUP_ACC", "0") != "1") else 1
+        algo = {"conv_fwd": fwd_flops * nfwd, "conv_dgrad": fwd_flops - stem_flops, "conv_wgrad": fwd_flops}
         kern = {}
         for k, (ms, calls) in prof.items():
             if calls:
@@ -254,15 +268,16 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": avg_us, "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
         lb = getattr(conv_flops_per_image, "layer_bytes", None)
-        if lb is not None and not is_vit and not is_cnx:
+        if lb is not None:
             # The same launches against the HBM roof: algorithmic bytes = each layer's input + output activations once
             # (bf16) + its filters (bf16 shadow read by fwd/dgrad; fp32 gradient written by wgrad).  ResNet's convolutions
             # have 64-512 channels, so most launches move more time's worth of bytes than of flops: report whichever roof
             # the class sits closer to, and keep the other fraction beside it.
             if dom == "conv_dgrad":
                 lb = lb[1:]
-            act = sum(i + o for i, o, _ in lb) * B
-            wts = sum(w for _, _, w in lb) * (4 if dom == "conv_wgrad" else 2)
+            passes = nfwd if dom == "conv_fwd" else 1
+            act = sum(i + o for i, o, _ in lb) * B * passes
+            wts = sum(w for _, _, w in lb) * (4 if dom == "conv_wgrad" else 2) * passes
             gbs = (act + wts) / (kern[dom]["ms_per_step"] * 1e-3) / 1e9
             roofline["mfma_frac"] = roofline["frac"]
             roofline["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
