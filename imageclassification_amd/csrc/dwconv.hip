@@ -182,16 +182,6 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const bf16_t* __rest
   }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_j part[j][i], fixed order
-__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ part, int nrows, long long n,
-                                                       float* __restrict__ out, int accumulate) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? out[i] : 0.f;
-  for (int j = 0; j < nrows; ++j) s += part[(long long)j * n + i];
-  out[i] = s;
-}
-
 // out = inp + keep[b] * gamma[c] * z      (rows_per_image rows of C channels per sample; keep may be NULL)
 __global__ __launch_bounds__(256) void layerscale_fwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ inp,
                                                              const float* __restrict__ gamma, const float* __restrict__ keep,

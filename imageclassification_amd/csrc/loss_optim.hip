@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
       __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
   cred[threadIdx.x] = correct;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) cred[threadIdx.x] += cred[threadIdx.x + o];
+    if ((int)threadIdx.x < o) cred[threadIdx.x] += cred[threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) {

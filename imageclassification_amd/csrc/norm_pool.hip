@@ -11,70 +11,6 @@
 
 namespace {
 
-// ------------------------------------------------------------------------------------------------
-// Two-level per-channel reduction of partial rows:  part[nrows][2][C] (fp32) -> out[nchunks][2][C] (fp64)
-// grid = (ceil(C/64), nchunks); block 1024 = 64 channels x 16 row lanes (short dependent chains: the kernel is
-// latency-bound, not bandwidth-bound)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ part, double* __restrict__ out,
-                                                              int nrows, int C, int rows_per_chunk) {
-  __shared__ double red[16][2][64];
-  const int cc = threadIdx.x & 63;
-  const int c = blockIdx.x * 64 + cc;
-  const int rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_chunk;
-  const int r1 = min(nrows, r0 + rows_per_chunk);
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C) {
-    for (int r = r0 + rl; r < r1; r += 16) {
-      s1 += (double)part[((long long)r * 2 + 0) * C + c];
-      s2 += (double)part[((long long)r * 2 + 1) * C + c];
-    }
-  }
-  red[rl][0][cc] = s1;
-  red[rl][1][cc] = s2;
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    const int which = threadIdx.x >> 6;
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s += red[j][which][cc];
-    if (c < C) out[((long long)blockIdx.y * 2 + which) * C + c] = s;
-  }
-}
-
-// BatchNorm training-mode finalize (torch.nn.functional.batch_norm semantics: biased variance for the
-// normalisation, unbiased for the running estimate, running = (1-mom)*running + mom*batch).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part2, int nchunks, int C,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, float momentum, float eps,
-                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                          float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
-    s1 += part2[((long long)k * 2 + 0) * C + c];
-    s2 += part2[((long long)k * 2 + 1) * C + c];
-  }
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float meanf = (float)mean;
-  mean_out[c] = meanf;
-  invstd_out[c] = invstd;
-  const float sc = gamma[c] * invstd;
-  scale_out[c] = sc;
-  shift_out[c] = beta[c] - meanf * sc;
-  if (running_mean != nullptr) {
-    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
 // eval-mode BN: scale/shift from the running estimates
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -310,24 +246,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     }
     __syncthreads();
   }
-}
-
-// BN backward finalize: dgamma = sum g*xhat, dbeta = sum g; coefficients for pass 2
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part2, int nchunks, int C,
-                                                              double count, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ c1_out,
-                                                              float* __restrict__ c2_out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int k = 0; k < nchunks; ++k) {
-    sg += part2[((long long)k * 2 + 0) * C + c];
-    sgx += part2[((long long)k * 2 + 1) * C + c];
-  }
-  c1_out[c] = (float)(sg / count);
-  c2_out[c] = (float)(sgx / count);
-  if (accumulate) { dgamma[c] += (float)sgx; dbeta[c] += (float)sg; }
-  else { dgamma[c] = (float)sgx; dbeta[c] = (float)sg; }
 }
 
 // BN backward, pass 2: dy = scale * (g - c1 - xhat*c2); optionally also stores g (masked dout) in gout
@@ -577,17 +495,6 @@ inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } retu
 }  // namespace
 
 // ---------------- host launchers (called from capi.hip) ----------------
-
-int icamd_partials_to_chunks(const float* part, int nrows, int C, double* chunks, int* nchunks_out, hipStream_t s) {
-  // at most 64 chunks (the finalize kernels walk them serially)
-  int rows_per_chunk = 128;
-  int nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk;
-  if (nchunks > 64) { nchunks = 64; rows_per_chunk = (nrows + 63) / 64; nchunks = (nrows + rows_per_chunk - 1) / rows_per_chunk; }
-  dim3 grid((unsigned)((C + 63) / 64), (unsigned)nchunks);
-  hipLaunchKernelGGL(partial_reduce_kernel, grid, dim3(1024), 0, s, part, chunks, nrows, C, rows_per_chunk);
-  *nchunks_out = nchunks;
-  return icamd_launch_status();
-}
 
 static void chunking(int nrows, int* rows_per_chunk, int* nchunks) {
   int rpc = 128;
