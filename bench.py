@@ -150,7 +150,7 @@ def main():
     from imageclassification_amd.ddp import DistributedDataParallel
     from imageclassification_amd.engine import train_one_epoch
     from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
-    from imageclassification_amd.nets import ARCHS, ResNet
+    from imageclassification_amd.nets import ResNet
     from imageclassification_amd.vit import CONFIGS as VIT_CONFIGS, VisionTransformer
     from imageclassification_amd.convnext import CONFIGS as CNX_CONFIGS, ConvNeXt
     from imageclassification_amd.ema import ModelEmaV3

@@ -13,7 +13,6 @@ convolution on the same tensor (bias fused); the depthwise stencil and the layer
 """
 import ctypes
 import os
-import math
 from collections import OrderedDict
 
 import torch

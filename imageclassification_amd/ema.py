@@ -5,8 +5,6 @@ timm semantics as recalled: an eval-mode deep copy; update() lerps EVERY floatin
 (parameters and BatchNorm running statistics) towards the model with weight 1-decay and copies integer
 buffers; decay is the constant 0.9995 the reference passes (no warm-up).  Here the parameter lerp is fused
 into the AdamW kernel (icamd_adamw_ema) and the buffer lerp is one icamd_lerp call."""
-import torch
-
 from . import hip
 
 

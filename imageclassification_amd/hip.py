@@ -5,7 +5,7 @@ compute path raises.  PyTorch is used for device memory (tensors), streams and t
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 import torch
 

@@ -7,8 +7,6 @@ it relies on is what torch runs for timm's layers under /root/reference/engine.p
 torch.optim.AdamW / timm ModelEmaV3 / timm Mixup (engine.py:44,68,74,77); torch-CPU is therefore the pin.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
-import math
-
 import torch
 import torch.nn.functional as F
 

@@ -12,7 +12,6 @@ checked in tests/test_oracle_cpu.py): "parity unpinned" with respect to timm, wh
 every stored activation-gradient rounded to bf16; accumulation, BatchNorm statistics and weight gradients in
 fp32), so that logits/gradients can be compared at the 1e-3 level instead of bf16's 4e-3 per-op noise.
 """
-import math
 
 import torch
 import torch.nn as nn
