@@ -120,23 +120,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   const float invC = 1.f / (float)C;
   const long long r0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
   const long long r1 = (rows < r0 + rows_per_wave) ? rows : r0 + rows_per_wave;
+  // Software-pipelined over rows: the raw vectors (dy, x, addend) and statistics of the NEXT row group are requested
+  // before the current one is reduced, so every wave keeps two rows of loads in flight (the kernel is latency-bound at
+  // the 12 waves per CU its registers allow).
+  u32x4 nd[2], nx[2], na[2];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](long long rbase) {
+    const long long row = rbase + grp;
+    const bool live = row < r1;
+    const long long ro = (live ? row : 0) * C;
+    nmu = live ? mean[row] : 0.f;
+    nrs = live ? rstd[row] : 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      nd[it] = u32x4{0u, 0u, 0u, 0u}; nx[it] = nd[it]; na[it] = nd[it];
+      if (has[it] && live) {
+        nd[it] = *(const u32x4*)(dy + ro + (sub + it * LPR) * 8);
+        nx[it] = *(const u32x4*)(x + ro + (sub + it * LPR) * 8);
+        if (addend != nullptr) na[it] = *(const u32x4*)(addend + ro + (sub + it * LPR) * 8);
+      }
+    }
+  };
+  if (r0 < r1) fetch(r0);
   for (long long rbase = r0; rbase < r1; rbase += RPW) {
     const long long row = rbase + grp;
     const bool live = row < r1;
     const long long ro = (live ? row : 0) * C;
-    const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+    const float mu = nmu, rs = nrs;
+    u32x4 rd[2], rx[2], ra[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { rd[it] = nd[it]; rx[it] = nx[it]; ra[it] = na[it]; }
+    if (rbase + RPW < r1) fetch(rbase + RPW);
     float dyg[2][8], xh[2][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      u32x4 rd = {0u, 0u, 0u, 0u}, rx = {0u, 0u, 0u, 0u};
-      if (has[it] && live) {
-        rd = *(const u32x4*)(dy + ro + (sub + it * LPR) * 8);
-        rx = *(const u32x4*)(x + ro + (sub + it * LPR) * 8);
-      }
       float d[8], xv[8];
-      unpack8(rd, d);
-      unpack8(rx, xv);
+      unpack8(rd[it], d);
+      unpack8(rx[it], xv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         xh[it][e] = (has[it] && live) ? (xv[e] - mu) * rs : 0.f;
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) o[e] = rs * (dyg[it][e] - c1 - xh[it][e] * c2);
         if (addend != nullptr) {   // residual branch: the skip connection's gradient joins here
           float a8[8];
-          unpack8(*(const u32x4*)(addend + ro + (sub + it * LPR) * 8), a8);
+          unpack8(ra[it], a8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += a8[e];
         }
