@@ -23,6 +23,8 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
                               long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s);
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s);
+int icamd_bn_relu_maxpool_fwd_launch(const bf16_t* y, const float* scale, const float* shift, bf16_t* out, unsigned char* idx,
+                                     int N, int IH, int IW, int C, int OH, int OW, hipStream_t s);
 int icamd_maxpool_bwd_launch(const bf16_t* dout, const unsigned char* idx, bf16_t* dx, int N, int IH, int IW, int C, int OH,
                              int OW, hipStream_t s);
 int icamd_avgpool_fwd_launch(const bf16_t* x, bf16_t* out, int N, int HW, int C, hipStream_t s);
@@ -643,6 +645,16 @@ int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int
   if (x == nullptr || out == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
   return icamd_maxpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, argmax, N, IH, IW, C, OH, OW, (hipStream_t)stream);
+}
+
+int icamd_bn_relu_maxpool3x3s2_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N,
+                                   int IH, int IW, int C, void* stream) {
+  ProfScope _prof(PC_BN_APPLY, stream);
+  if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
+  return icamd_bn_relu_maxpool_fwd_launch((const bf16_t*)y, scale, shift, (bf16_t*)out, argmax, N, IH, IW, C, OH, OW,
+                                          (hipStream_t)stream);
 }
 
 int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream) {

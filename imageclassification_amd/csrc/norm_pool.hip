@@ -312,9 +312,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------------
 // max-pool 3x3 stride 2 pad 1 (torch scan order: rows then columns, first maximum wins, NaN propagates)
 // ------------------------------------------------------------------------------------------------
+// BNRELU: x is a raw conv output; every window element is first mapped to bf16(relu(x*scale[c] + shift[c])) -- exactly the
+// tensor icamd_bn_apply would have stored -- so BatchNorm-apply + ReLU + max-pool of the ResNet stem is one pass that
+// reads the conv output once and never writes the full-resolution activation.
+template <bool BNRELU>
 __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                                unsigned char* __restrict__ idx, int N, int IH, int IW,
-                                                               int C, int OH, int OW) {
+                                                               int C, int OH, int OW, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift) {
   const int cpr = C >> 3;
   const long long total = (long long)N * OH * OW * cpr;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -341,6 +346,14 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const bf16_t* __r
         float f[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(v[e]); f[2 * e + 1] = bf16_hi(v[e]); }
+        if constexpr (BNRELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = fmaf(f[e], scale[cg * 8 + e], shift[cg * 8 + e]);
+            a = a < 0.f ? 0.f : a;
+            f[e] = bf16_to_f32(f32_to_bf16(a));
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           if (first || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = r * 3 + s; }
@@ -622,8 +635,17 @@ int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, i
                              hipStream_t s) {
   if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
   const long long total = (long long)N * OH * OW * (C / 8);
-  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, x, out, idx, N, IH, IW, C,
-                     OH, OW);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<false>, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, x, out, idx, N, IH, IW,
+                     C, OH, OW, nullptr, nullptr);
+  return icamd_launch_status();
+}
+
+int icamd_bn_relu_maxpool_fwd_launch(const bf16_t* y, const float* scale, const float* shift, bf16_t* out, unsigned char* idx,
+                                     int N, int IH, int IW, int C, int OH, int OW, hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)N * OH * OW * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<true>, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, y, out, idx, N, IH, IW,
+                     C, OH, OW, scale, shift);
   return icamd_launch_status();
 }
 

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "icamd_attention_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "icamd_attention_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     "icamd_maxpool3x3s2_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "icamd_bn_relu_maxpool3x3s2_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "icamd_maxpool3x3s2_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "icamd_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "icamd_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),

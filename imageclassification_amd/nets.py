@@ -541,6 +541,8 @@ class ResNet:
             shift = scale + 4 * 2048
             hip.check(lib.icamd_bn_eval_coeffs(c, self._pf(bn.weight), self._pf(bn.bias), rm, rm + 4 * c, BN_EPS, scale,
                                                shift, s), bn.name)
+        if out is None:      # the caller fuses the apply into its own kernel (stem: BN + ReLU + max-pool)
+            return d, scale, shift
         hip.check(lib.icamd_bn_apply(y.data_ptr(), scale, shift, residual, out.data_ptr(), maskbits, y.numel(), c, int(relu),
                                      s), bn.name)
         return d
@@ -563,11 +565,13 @@ class ResNet:
             return self._forward_eval_folded(ws)
         if self.training:
             self.num_batches_tracked += 1
-        d0 = self._conv_bn_fwd(ws, self.stem_conv, self.stem_bn, ws["x8"].data_ptr(), N, H, W, ws["y0"], ws["a0"], None,
-                               True, s)
-        hip.check(lib.icamd_maxpool3x3s2_fwd(ws["a0"].data_ptr(), ws["p0"].data_ptr(),
-                                             ws["p0_idx"].data_ptr() if self.training else None, N, d0.OH, d0.OW, 64, s),
-                  "maxpool")
+        # stem: conv -> BatchNorm + ReLU + max-pool in one pass over the conv output (the 112x112 activation is never
+        # stored: backward recomputes the ReLU mask from y0 and the pooling argmax is recorded)
+        d0, sc0, sh0 = self._conv_bn_fwd(ws, self.stem_conv, self.stem_bn, ws["x8"].data_ptr(), N, H, W, ws["y0"], None, None,
+                                         True, s)
+        hip.check(lib.icamd_bn_relu_maxpool3x3s2_fwd(ws["y0"].data_ptr(), sc0, sh0, ws["p0"].data_ptr(),
+                                                     ws["p0_idx"].data_ptr() if self.training else None, N, d0.OH, d0.OW, 64,
+                                                     s), "stem bn+relu+maxpool")
         x = ws["p0"]
         h, w = x.shape[1], x.shape[2]
         for blk, b in zip(self.blocks, ws["blocks"]):

@@ -196,6 +196,11 @@ int icamd_attention_bwd(const void* qkv, const void* out, const void* dout, cons
 
 /* ---- pooling ---------------------------------------------------------------------------------------- */
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream);
+/* ResNet stem in training: BatchNorm-apply + ReLU + max-pool 3x3/2 in one pass over the conv output y.  Bit-identical
+ * to icamd_bn_apply(relu) followed by icamd_maxpool3x3s2_fwd (every window element is rounded to bf16 as the stored
+ * activation would have been); the full-resolution activation is never written. */
+int icamd_bn_relu_maxpool3x3s2_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N,
+                                   int IH, int IW, int C, void* stream);
 int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream);
 int icamd_avgpool_fwd(const void* x, void* out, int N, int HW, int C, void* stream);
 int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* stream);

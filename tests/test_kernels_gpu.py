@@ -484,6 +484,29 @@ def test_maxpool(lib, shape):
     assert R.max_bf16_ulp(got, rdx) <= 1.0 and R.rel_l2(got, rdx) <= 1e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 12, 64), (3, 9, 11, 64), (1, 16, 16, 128)])
+def test_bn_relu_maxpool_fused_is_bit_identical(lib, shape):
+    """Stem fusion: BatchNorm-apply + ReLU + max-pool in one pass == icamd_bn_apply followed by icamd_maxpool3x3s2_fwd
+    (values and recorded argmax), odd sizes included."""
+    hip = _hip()
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(90)
+    y = to_dev_bf16(rnd_bf16(N, H, W, C, seed=91))
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    act = torch.empty_like(y)
+    p1 = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=DEV); p2 = torch.empty_like(p1)
+    i1 = torch.zeros(N, OH, OW, C, dtype=torch.uint8, device=DEV); i2 = torch.ones_like(i1)
+    s = hip.stream_ptr()
+    assert lib.icamd_bn_apply(hip.ptr(y), hip.ptr(scale), hip.ptr(shift), None, hip.ptr(act), None, y.numel(), C, 1, s) == 0
+    assert lib.icamd_maxpool3x3s2_fwd(hip.ptr(act), hip.ptr(p1), hip.ptr(i1), N, H, W, C, s) == 0
+    assert lib.icamd_bn_relu_maxpool3x3s2_fwd(hip.ptr(y), hip.ptr(scale), hip.ptr(shift), hip.ptr(p2), hip.ptr(i2), N, H, W, C,
+                                              s) == 0
+    sync()
+    assert torch.equal(p1, p2) and torch.equal(i1, i2)
+
+
 def test_avgpool(lib):
     hip = _hip()
     N, HW, C = 6, 49, 2048
