@@ -12,7 +12,8 @@ int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, 
 int icamd_bn_eval_coeffs_launch(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                 float* scale, float* shift, hipStream_t s);
 int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shift, const bf16_t* residual, bf16_t* out,
-                          unsigned char* maskbits, long long numel, int C, int relu, hipStream_t s);
+                          unsigned char* maskbits, long long numel, int C, int relu, hipStream_t s,
+                          const float* res_scale = nullptr, const float* res_shift = nullptr);
 int icamd_bn_bwd_rows_per_block(long long rows, int C);
 int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
@@ -399,6 +400,17 @@ int icamd_bn_apply(const void* y, const float* scale, const float* shift, const 
   if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || numel <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)residual, (bf16_t*)out, maskbits, numel, C,
                                relu, (hipStream_t)stream);
+}
+
+int icamd_bn_apply_res_bn(const void* y, const float* scale, const float* shift, const void* res_y, const float* res_scale,
+                          const float* res_shift, void* out, uint8_t* maskbits, long long numel, int C, int relu,
+                          void* stream) {
+  ProfScope _prof(PC_BN_APPLY, stream);
+  if (y == nullptr || scale == nullptr || shift == nullptr || res_y == nullptr || res_scale == nullptr ||
+      res_shift == nullptr || out == nullptr || numel <= 0 || C <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)res_y, (bf16_t*)out, maskbits, numel, C, relu,
+                               (hipStream_t)stream, res_scale, res_shift);
 }
 
 // bwd workspace: partial rows [nblk][2][C] floats | chunks [64][2][C] doubles | c1,c2 [2][C] floats

@@ -129,14 +129,21 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bf16_t* __restrict__ residual,
                                                        bf16_t* __restrict__ out, unsigned char* __restrict__ maskbits,
-                                                       long long nvec, int cpr, int relu) {
+                                                       long long nvec, int cpr, int relu,
+                                                       const float* __restrict__ res_scale,
+                                                       const float* __restrict__ res_shift) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // the launcher makes stride a multiple of cpr, so this thread's channel group never changes
   const int cg = (int)(i % cpr) * 8;
-  float sc[8], sh[8];
+  float sc[8], sh[8], rsc[8], rsh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = scale[cg + e]; sh[e] = shift[cg + e]; }
+  // res_scale != nullptr: `residual` is the RAW conv output of the shortcut branch and its BatchNorm (no ReLU) is applied
+  // here, rounded to bf16 exactly as the stored shortcut activation would have been
+  const bool res_bn = res_scale != nullptr;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { rsc[e] = res_bn ? res_scale[cg + e] : 1.f; rsh[e] = res_bn ? res_shift[cg + e] : 0.f; }
   for (; i < nvec; i += stride) {
     const u32x4 v = ((const u32x4*)y)[i];
     float f[8];
@@ -147,8 +154,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     }
     if (residual != nullptr) {
       const u32x4 r = ((const u32x4*)residual)[i];
+      if (res_bn) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { f[2 * e] += bf16_lo(r[e]); f[2 * e + 1] += bf16_hi(r[e]); }
+        for (int e = 0; e < 4; ++e) {
+          f[2 * e] += bf16_to_f32(f32_to_bf16(fmaf(bf16_lo(r[e]), rsc[2 * e], rsh[2 * e])));
+          f[2 * e + 1] += bf16_to_f32(f32_to_bf16(fmaf(bf16_hi(r[e]), rsc[2 * e + 1], rsh[2 * e + 1])));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[2 * e] += bf16_lo(r[e]); f[2 * e + 1] += bf16_hi(r[e]); }
+      }
     }
     if (relu) {
 #pragma unroll
@@ -560,12 +575,13 @@ static unsigned int elementwise_grid(long long nvec, int cpr) {
 }
 
 int icamd_bn_apply_launch(const bf16_t* y, const float* scale, const float* shift, const bf16_t* residual, bf16_t* out,
-                          unsigned char* maskbits, long long numel, int C, int relu, hipStream_t s) {
+                          unsigned char* maskbits, long long numel, int C, int relu, hipStream_t s,
+                          const float* res_scale, const float* res_shift) {
   if (C % 8 != 0 || numel % C != 0) return ICAMD_ERR_BAD_ARG;
   const long long nvec = numel / 8;
   const int cpr = C / 8;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(elementwise_grid(nvec, cpr)), dim3(256), 0, s, y, scale, shift, residual, out,
-                     maskbits, nvec, cpr, relu);
+                     maskbits, nvec, cpr, relu, res_scale, res_shift);
   return icamd_launch_status();
 }
 

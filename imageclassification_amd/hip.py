@@ -59,6 +59,7 @@ _SIGNATURES = {
     "icamd_bn_train_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "icamd_bn_eval_coeffs": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "icamd_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
+    "icamd_bn_apply_res_bn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "icamd_bn_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "icamd_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_size_t, _P]),
     "icamd_bn_bwd_apply_workspace_bytes": (c_size_t, [c_int]),

@@ -519,7 +519,7 @@ class ResNet:
     def _gf(self, p):  # fp32 grad pointer
         return self.grad_arena.data_ptr() + 4 * p.offset
 
-    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s, maskbits=None):
+    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s, maskbits=None, res_bn=None):
         """y = conv(x); out = act(bn(y) (+ residual)). Training: batch statistics from the conv epilogue."""
         lib = self.lib
         d = conv.desc(N, IH, IW)
@@ -543,6 +543,10 @@ class ResNet:
                                                shift, s), bn.name)
         if out is None:      # the caller fuses the apply into its own kernel (stem: BN + ReLU + max-pool)
             return d, scale, shift
+        if res_bn is not None:   # residual = raw shortcut conv output; its BatchNorm is applied inside the same pass
+            hip.check(lib.icamd_bn_apply_res_bn(y.data_ptr(), scale, shift, residual, res_bn[0], res_bn[1], out.data_ptr(),
+                                                maskbits, y.numel(), c, int(relu), s), bn.name)
+            return d
         hip.check(lib.icamd_bn_apply(y.data_ptr(), scale, shift, residual, out.data_ptr(), maskbits, y.numel(), c, int(relu),
                                      s), bn.name)
         return d
@@ -578,7 +582,14 @@ class ResNet:
             b["in"] = x
             b["in_hw"] = (h, w)
             convs, bns = blk["convs"], blk["bns"]
-            if "down_conv" in blk:
+            res_bn = None
+            if "down_conv" in blk and self.training:
+                # shortcut conv + statistics only: its BatchNorm is applied inside the block's last BatchNorm pass, the
+                # normalised shortcut is never stored (backward needs yd and the block mask, not it)
+                _, scd, shd = self._conv_bn_fwd(ws, blk["down_conv"], blk["down_bn"], x.data_ptr(), N, h, w, b["yd"], None,
+                                                None, False, s)
+                idn, res_bn = b["yd"], (scd, shd)
+            elif "down_conv" in blk:
                 self._conv_bn_fwd(ws, blk["down_conv"], blk["down_bn"], x.data_ptr(), N, h, w, b["yd"], b["ad"], None,
                                   False, s)
                 idn = b["ad"]
@@ -589,7 +600,8 @@ class ResNet:
                 last = i == len(convs) - 1
                 d = self._conv_bn_fwd(ws, conv, bn, cur.data_ptr(), N, ch, cw, b["y"][i], b["a"][i],
                                       idn.data_ptr() if last else None, True, s,
-                                      b["mask"].data_ptr() if (last and self.training) else None)
+                                      b["mask"].data_ptr() if (last and self.training) else None,
+                                      res_bn if last else None)
                 cur, ch, cw = b["a"][i], d.OH, d.OW
             x, h, w = cur, ch, cw
         hip.check(lib.icamd_avgpool_fwd(x.data_ptr(), ws["pooled"].data_ptr(), N, h * w, self.feat_dim, s), "avgpool")

@@ -126,6 +126,12 @@ int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const flo
  * maskbits (optional, numel/8 bytes): bit k of byte i <- [out[8i+k] > 0], the ReLU mask for the backward pass. */
 int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                    uint8_t* maskbits, long long numel, int C, int relu, void* stream);
+/* Same with the residual given as the RAW conv output of the shortcut (downsample) branch: its BatchNorm (no ReLU) is
+ * applied on the fly, residual = bf16(res_y * res_scale[c] + res_shift[c]) -- bit-identical to running icamd_bn_apply on
+ * the shortcut first, without writing and re-reading that activation. */
+int icamd_bn_apply_res_bn(const void* y, const float* scale, const float* shift, const void* res_y, const float* res_scale,
+                          const float* res_shift, void* out, uint8_t* maskbits, long long numel, int C, int relu,
+                          void* stream);
 size_t icamd_bn_bwd_workspace_bytes(long long rows, int C);
 /* g = dout * mask, mask (when relu) = maskbits if given, else [act > 0] if act given, else [y*scale+shift > 0];
  * dgamma = sum g*xhat, dbeta = sum g, dy = scale*(g - mean(g) - xhat*mean(g*xhat)); gout (optional) <- g */

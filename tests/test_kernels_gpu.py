@@ -484,6 +484,26 @@ def test_maxpool(lib, shape):
     assert R.max_bf16_ulp(got, rdx) <= 1.0 and R.rel_l2(got, rdx) <= 1e-3
 
 
+def test_bn_apply_with_shortcut_batchnorm_is_bit_identical(lib):
+    """Residual given as the raw shortcut conv output + its BatchNorm coefficients == BatchNorm-apply on the shortcut
+    followed by the residual BatchNorm-apply (output and ReLU mask bits)."""
+    hip = _hip()
+    N, H, W, C = 3, 7, 9, 256
+    g = torch.Generator().manual_seed(95)
+    y = to_dev_bf16(rnd_bf16(N, H, W, C, seed=96)); yd = to_dev_bf16(rnd_bf16(N, H, W, C, seed=97))
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    scd, shd = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    ad = torch.empty_like(y); o1 = torch.empty_like(y); o2 = torch.empty_like(y)
+    m1 = torch.zeros(y.numel() // 8, dtype=torch.uint8, device=DEV); m2 = torch.ones_like(m1)
+    s = hip.stream_ptr()
+    assert lib.icamd_bn_apply(hip.ptr(yd), hip.ptr(scd), hip.ptr(shd), None, hip.ptr(ad), None, y.numel(), C, 0, s) == 0
+    assert lib.icamd_bn_apply(hip.ptr(y), hip.ptr(sc), hip.ptr(sh), hip.ptr(ad), hip.ptr(o1), hip.ptr(m1), y.numel(), C, 1, s) == 0
+    assert lib.icamd_bn_apply_res_bn(hip.ptr(y), hip.ptr(sc), hip.ptr(sh), hip.ptr(yd), hip.ptr(scd), hip.ptr(shd), hip.ptr(o2),
+                                     hip.ptr(m2), y.numel(), C, 1, s) == 0
+    sync()
+    assert torch.equal(o1, o2) and torch.equal(m1, m2)
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 12, 64), (3, 9, 11, 64), (1, 16, 16, 128)])
 def test_bn_relu_maxpool_fused_is_bit_identical(lib, shape):
     """Stem fusion: BatchNorm-apply + ReLU + max-pool in one pass == icamd_bn_apply followed by icamd_maxpool3x3s2_fwd
