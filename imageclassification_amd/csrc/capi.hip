@@ -19,6 +19,11 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
                         const unsigned char* maskbits, long long rows, int C, int relu, int accumulate, float* part,
                         double* chunks, float* c1c2, hipStream_t s);
+int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, const bf16_t* yA, const float* meanA,
+                             const float* invstdA, const float* scaleA, float* dgammaA, float* dbetaA, bf16_t* dyA,
+                             const bf16_t* yB, const float* meanB, const float* invstdB, const float* scaleB, float* dgammaB,
+                             float* dbetaB, bf16_t* dyB, long long rows, int C, int accumulate, float* partA, double* chunksA,
+                             float* cA, float* partB, double* chunksB, float* cB, hipStream_t s);
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
                               const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
                               long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s);
@@ -443,6 +448,35 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
   return icamd_bn_bwd_launch((const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, mean, invstd, scale, shift, dgamma,
                              dbeta, (bf16_t*)dy, (bf16_t*)gout, maskbits, rows, C, relu, accumulate, part, chunks, c1c2,
                              (hipStream_t)stream);
+}
+
+int icamd_bn_bwd_dual(const void* dout, const uint8_t* maskbits, const void* yA, const float* meanA, const float* invstdA,
+                      const float* scaleA, float* dgammaA, float* dbetaA, void* dyA, const void* yB, const float* meanB,
+                      const float* invstdB, const float* scaleB, float* dgammaB, float* dbetaB, void* dyB, long long rows, int C,
+                      int accumulate, void* workspaceA, void* workspaceB, size_t workspace_bytes, void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (dout == nullptr || maskbits == nullptr || yA == nullptr || yB == nullptr || meanA == nullptr || meanB == nullptr ||
+      invstdA == nullptr || invstdB == nullptr || scaleA == nullptr || scaleB == nullptr || dgammaA == nullptr ||
+      dgammaB == nullptr || dbetaA == nullptr || dbetaB == nullptr || dyA == nullptr || dyB == nullptr ||
+      workspaceA == nullptr || workspaceB == nullptr || workspaceA == workspaceB || rows <= 0 || C <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < icamd_bn_bwd_workspace_bytes(rows, C)) return ICAMD_ERR_WORKSPACE;
+  if (C > 4096) return ICAMD_ERR_UNSUPPORTED;
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const long long nblk = (rows + rpb - 1) / rpb;
+  float* part[2]; double* chunks[2]; float* cc[2];
+  void* wsv[2] = {workspaceA, workspaceB};
+  for (int i = 0; i < 2; ++i) {
+    char* ws = (char*)wsv[i];
+    chunks[i] = (double*)(ws + 256);
+    ws += bn_chunk_bytes(C);
+    part[i] = (float*)ws;
+    ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
+    cc[i] = (float*)ws;
+  }
+  return icamd_bn_bwd_dual_launch((const bf16_t*)dout, maskbits, (const bf16_t*)yA, meanA, invstdA, scaleA, dgammaA, dbetaA,
+                                  (bf16_t*)dyA, (const bf16_t*)yB, meanB, invstdB, scaleB, dgammaB, dbetaB, (bf16_t*)dyB, rows,
+                                  C, accumulate, part[0], chunks[0], cc[0], part[1], chunks[1], cc[1], (hipStream_t)stream);
 }
 
 // workspace: chunks [64][2][C] doubles | c1,c2 [2][C] floats

@@ -325,6 +325,118 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two BatchNorm backward passes that share one masked output gradient: a ResNet block with a projection shortcut feeds
+// g = dout * [block output > 0] into BOTH the block's last BatchNorm (conv output yA) and the shortcut's BatchNorm (yB).
+// Done as two separate icamd_bn_bwd calls, dout and its mask bits are read four times; here twice.
+//   reduce: partA[blk] = (sum g, sum g*xhatA), partB[blk] = (sum g, sum g*xhatB)   (same layout as bn_bwd_reduce_kernel)
+//   apply : dyA = scaleA*(g - c1A - xhatA*c2A), dyB likewise
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_dual_reduce_kernel(const bf16_t* __restrict__ dout,
+                                                                 const unsigned char* __restrict__ maskbits,
+                                                                 const bf16_t* __restrict__ yA, const float* __restrict__ meanA,
+                                                                 const float* __restrict__ invstdA,
+                                                                 const bf16_t* __restrict__ yB, const float* __restrict__ meanB,
+                                                                 const float* __restrict__ invstdB, float* __restrict__ partA,
+                                                                 float* __restrict__ partB, long long rows, int C,
+                                                                 int rows_per_block) {
+  __shared__ float red[256 * 24];
+  const int cpr = C >> 3;
+  const int tid = threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = (rows < r0 + rows_per_block) ? rows : r0 + rows_per_block;
+  for (int cg0 = 0; cg0 < cpr; cg0 += 256) {
+    const int tcols = (cpr - cg0 < 256) ? (cpr - cg0) : 256;
+    const int rlanes = 256 / tcols;
+    const int cgi = tid % tcols, rl = tid / tcols;
+    float sg[8], sa[8], sb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sa[e] = 0.f; sb[e] = 0.f; }
+    if (rl < rlanes) {
+      const int c = (cg0 + cgi) * 8;
+      float muA[8], isA[8], muB[8], isB[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { muA[e] = meanA[c + e]; isA[e] = invstdA[c + e]; muB[e] = meanB[c + e]; isB[e] = invstdB[c + e]; }
+      for (long long r = r0 + rl; r < r1; r += rlanes) {
+        const long long off = r * cpr + cg0 + cgi;
+        const u32x4 d = ((const u32x4*)dout)[off];
+        const u32x4 va = ((const u32x4*)yA)[off];
+        const u32x4 vb = ((const u32x4*)yB)[off];
+        const unsigned int bits = maskbits[off];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned int wd = d[e >> 1], wa = va[e >> 1], wb = vb[e >> 1];
+          float g = (e & 1) ? bf16_hi(wd) : bf16_lo(wd);
+          if (!((bits >> e) & 1u)) g = 0.f;
+          const float ya = (e & 1) ? bf16_hi(wa) : bf16_lo(wa), yb = (e & 1) ? bf16_hi(wb) : bf16_lo(wb);
+          sg[e] += g;
+          sa[e] += g * ((ya - muA[e]) * isA[e]);
+          sb[e] += g * ((yb - muB[e]) * isB[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 24 + e] = sg[e]; red[tid * 24 + 8 + e] = sa[e]; red[tid * 24 + 16 + e] = sb[e]; }
+    __syncthreads();
+    for (int o = tid; o < tcols * 24; o += 256) {
+      const int cgo = o / 24, e = o - cgo * 24;
+      float s = 0.f;
+      for (int l = 0; l < rlanes; ++l) s += red[(l * tcols + cgo) * 24 + e];
+      const int ch = (cg0 + cgo) * 8 + (e & 7);
+      if (e < 8) {
+        partA[((long long)blockIdx.x * 2 + 0) * C + ch] = s;
+        partB[((long long)blockIdx.x * 2 + 0) * C + ch] = s;
+      } else if (e < 16) {
+        partA[((long long)blockIdx.x * 2 + 1) * C + ch] = s;
+      } else {
+        partB[((long long)blockIdx.x * 2 + 1) * C + ch] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(const bf16_t* __restrict__ dout,
+                                                                const unsigned char* __restrict__ maskbits,
+                                                                const bf16_t* __restrict__ yA, const float* __restrict__ meanA,
+                                                                const float* __restrict__ invstdA, const float* __restrict__ scaleA,
+                                                                const float* __restrict__ cA, bf16_t* __restrict__ dyA,
+                                                                const bf16_t* __restrict__ yB, const float* __restrict__ meanB,
+                                                                const float* __restrict__ invstdB, const float* __restrict__ scaleB,
+                                                                const float* __restrict__ cB, bf16_t* __restrict__ dyB,
+                                                                long long nvec, int cpr, int C) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)(i % cpr) * 8;
+  float muA[8], isA[8], scA[8], k1A[8], k2A[8], muB[8], isB[8], scB[8], k1B[8], k2B[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    muA[e] = meanA[cg + e]; isA[e] = invstdA[cg + e]; scA[e] = scaleA[cg + e]; k1A[e] = cA[cg + e]; k2A[e] = cA[C + cg + e];
+    muB[e] = meanB[cg + e]; isB[e] = invstdB[cg + e]; scB[e] = scaleB[cg + e]; k1B[e] = cB[cg + e]; k2B[e] = cB[C + cg + e];
+  }
+  for (; i < nvec; i += stride) {
+    const u32x4 d = ((const u32x4*)dout)[i];
+    const u32x4 va = ((const u32x4*)yA)[i];
+    const u32x4 vb = ((const u32x4*)yB)[i];
+    const unsigned int bits = maskbits[i];
+    float oa[8], ob[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned int wd = d[e >> 1], wa = va[e >> 1], wb = vb[e >> 1];
+      float g = (e & 1) ? bf16_hi(wd) : bf16_lo(wd);
+      if (!((bits >> e) & 1u)) g = 0.f;
+      const float ya = (e & 1) ? bf16_hi(wa) : bf16_lo(wa), yb = (e & 1) ? bf16_hi(wb) : bf16_lo(wb);
+      oa[e] = scA[e] * (g - k1A[e] - ((ya - muA[e]) * isA[e]) * k2A[e]);
+      ob[e] = scB[e] * (g - k1B[e] - ((yb - muB[e]) * isB[e]) * k2B[e]);
+    }
+    u32x4 pa, pb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pa[e] = pack_bf16x2(oa[2 * e], oa[2 * e + 1]); pb[e] = pack_bf16x2(ob[2 * e], ob[2 * e + 1]); }
+    ((u32x4*)dyA)[i] = pa;
+    ((u32x4*)dyB)[i] = pb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // max-pool 3x3 stride 2 pad 1 (torch scan order: rows then columns, first maximum wins, NaN propagates)
 // ------------------------------------------------------------------------------------------------
 // BNRELU: x is a raw conv output; every window element is first mapped to bf16(relu(x*scale[c] + shift[c])) -- exactly the
@@ -620,6 +732,36 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, act, y, mean, invstd,
                      scale, shift, c1, c2, dy, gout, maskbits, nvec, C / 8, relu);
+  return icamd_launch_status();
+}
+
+int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, const bf16_t* yA, const float* meanA,
+                             const float* invstdA, const float* scaleA, float* dgammaA, float* dbetaA, bf16_t* dyA,
+                             const bf16_t* yB, const float* meanB, const float* invstdB, const float* scaleB, float* dgammaB,
+                             float* dbetaB, bf16_t* dyB, long long rows, int C, int accumulate, float* partA, double* chunksA,
+                             float* cA, float* partB, double* chunksB, float* cB, hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const int nblk = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_bwd_dual_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dout, maskbits, yA, meanA, invstdA, yB,
+                     meanB, invstdB, partA, partB, rows, C, rpb);
+  int rc = icamd_launch_status();
+  if (rc) return rc;
+  int rpc, nc;
+  chunking(nblk, &rpc, &nc);
+  for (int which = 0; which < 2; ++which) {
+    BnFinalizeArgs a = {};
+    a.dgamma = which ? dgammaB : dgammaA; a.dbeta = which ? dbetaB : dbetaA;
+    a.c1_out = which ? cB : cA; a.c2_out = (which ? cB : cA) + C; a.accumulate = accumulate; a.count = (double)rows;
+    double* chunks = which ? chunksB : chunksA;
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)((C + 63) / 64), (unsigned)nc), dim3(1024), 0, s,
+                       which ? partB : partA, chunks, counters_of(chunks, C), nblk, C, rpc, a);
+    rc = icamd_launch_status();
+    if (rc) return rc;
+  }
+  const long long nvec = rows * (C / 8);
+  hipLaunchKernelGGL(bn_bwd_dual_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, maskbits, yA, meanA,
+                     invstdA, scaleA, cA, dyA, yB, meanB, invstdB, scaleB, cB, dyB, nvec, C / 8, C);
   return icamd_launch_status();
 }
 

@@ -25,6 +25,7 @@ from . import hip
 BN_EPS = 1e-5
 _FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
 _WGRAD_STREAM = os.environ.get("ICAMD_WGRAD_STREAM", "1") != "0"
+_DUAL_BNBWD = os.environ.get("ICAMD_DUAL_BNBWD", "1") != "0"
 BN_MOMENTUM = 0.1
 
 ARCHS = {
@@ -487,6 +488,7 @@ class ResNet:
         ws["bna_ws_bytes"] = lib.icamd_bn_bwd_apply_workspace_bytes(2048)
         ws["bna_ws"] = torch.zeros(ws["bna_ws_bytes"], dtype=torch.uint8, device=dev)
         ws["bnb_ws"] = torch.zeros(max_bnb, dtype=torch.uint8, device=dev)
+        ws["bnb_ws2"] = torch.zeros(max_bnb, dtype=torch.uint8, device=dev)   # second BatchNorm of icamd_bn_bwd_dual
         ws["bnb_ws_bytes"] = max_bnb
         ws["max_act"] = max_act
         # loss / metric scratch
@@ -714,7 +716,22 @@ class ResNet:
             # never written: the shortcut consumers below re-apply the same bits to `dout`
             mask = b["mask"].data_ptr()
             yk = next_y()
-            bn_bwd(bns[-1], dout, None, b["y"][-1], ypool[yk], None, True, mask)
+            y2 = None
+            if "down_conv" in blk and _DUAL_BNBWD:
+                # the block's last BatchNorm and its shortcut's BatchNorm take the same masked gradient: one reduce and one
+                # apply pass for both (dout and the mask bits are read twice instead of four times)
+                y2 = next_y()
+                bnA, bnB = bns[-1], blk["down_bn"]
+                stA = self.stat_arena.data_ptr() + 4 * bnA.stat_offset
+                stB = self.stat_arena.data_ptr() + 4 * bnB.stat_offset
+                c = bnA.c
+                hip.check(lib.icamd_bn_bwd_dual(dout, mask, b["y"][-1].data_ptr(), stA, stA + 4 * c, stA + 8 * c,
+                                                self._gf(bnA.weight), self._gf(bnA.bias), ypool[yk], b["yd"].data_ptr(), stB,
+                                                stB + 4 * c, stB + 8 * c, self._gf(bnB.weight), self._gf(bnB.bias), ypool[y2],
+                                                b["y"][-1].numel() // c, c, acc, bws, ws["bnb_ws2"].data_ptr(), bwb, s),
+                          bnA.name + " + shortcut bwd")
+            else:
+                bn_bwd(bns[-1], dout, None, b["y"][-1], ypool[yk], None, True, mask)
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
                 # wgrad first: measured, it overlaps best with the data-gradient kernel of the same layer (issued after it,
@@ -726,8 +743,9 @@ class ResNet:
                 bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], ypool[yk], None, True)
             wgrad(convs[0], xin.data_ptr(), ypool[yk], N, h, w, ybuf=yk)
             if "down_conv" in blk:
-                y2 = next_y()
-                bn_bwd(blk["down_bn"], dout, None, b["yd"], ypool[y2], None, True, mask)   # "relu" = the block's mask bits
+                if y2 is None:
+                    y2 = next_y()
+                    bn_bwd(blk["down_bn"], dout, None, b["yd"], ypool[y2], None, True, mask)   # "relu" = the block's mask bits
                 wgrad(blk["down_conv"], xin.data_ptr(), ypool[y2], N, h, w, ybuf=y2)
                 dgrad(blk["down_conv"], ypool[y2], T, None, N, h, w)
                 dgrad(convs[0], ypool[yk], other, T, N, h, w)

@@ -139,6 +139,14 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
                  const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
                  const uint8_t* maskbits, long long rows, int C, int relu, int accumulate, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* Two BatchNorm backward passes over ONE masked output gradient g = dout * maskbits: the last BatchNorm of a residual block
+ * (conv output yA) and the BatchNorm of its projection shortcut (yB), /root/reference's timm Bottleneck/BasicBlock with
+ * `downsample`.  Same results as two icamd_bn_bwd calls (relu = 1, maskbits given); dout and the bits are read twice instead
+ * of four times.  Two distinct zero-initialised workspaces of icamd_bn_bwd_workspace_bytes(rows, C) each. */
+int icamd_bn_bwd_dual(const void* dout, const uint8_t* maskbits, const void* yA, const float* meanA, const float* invstdA,
+                      const float* scaleA, float* dgammaA, float* dbetaA, void* dyA, const void* yB, const float* meanB,
+                      const float* invstdB, const float* scaleB, float* dgammaB, float* dbetaB, void* dyB, long long rows, int C,
+                      int accumulate, void* workspaceA, void* workspaceB, size_t workspace_bytes, void* stream);
 
 /* second half of the fused form: finalize (dgamma, dbeta, means) + dy = scale*(g - mean(g) - xhat*mean(g*xhat)) */
 size_t icamd_bn_bwd_apply_workspace_bytes(int C);

@@ -460,6 +460,51 @@ def test_bn_train_apply_and_bwd(lib, shape):
     assert R.rel_l2(rdg, gt.grad) <= 1e-4 and R.rel_l2(rdb, bt.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("shape", [(4, 6, 6, 64), (3, 7, 5, 256), (2, 3, 3, 2048)])
+def test_bn_bwd_dual_matches_two_calls(lib, shape):
+    """Block-output BatchNorm + shortcut BatchNorm backward in one reduce and one apply pass == two icamd_bn_bwd calls with
+    the same mask bits: data gradients bit-identical, dgamma / dbeta equal, with and without accumulation."""
+    hip = _hip()
+    N, H, W, C = shape
+    rows = N * H * W
+    g = torch.Generator().manual_seed(120)
+    dout = to_dev_bf16(rnd_bf16(N, H, W, C, seed=121))
+    yA, yB = to_dev_bf16(rnd_bf16(N, H, W, C, seed=122)), to_dev_bf16(rnd_bf16(N, H, W, C, seed=123))
+    bits = torch.randint(0, 256, (rows * C // 8,), generator=g, dtype=torch.uint8).to(DEV)
+    st = {}
+    for k in ("A", "B"):
+        st[k] = [t.to(DEV) for t in (torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5,
+                                     torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1)]   # mean invstd scale shift
+    wsb = lib.icamd_bn_bwd_workspace_bytes(rows, C)
+    ws = [torch.zeros(wsb, dtype=torch.uint8, device=DEV) for _ in range(4)]
+    s = hip.stream_ptr()
+    for accum in (0, 1):
+        ref, got = {}, {}
+        for k, y, w in (("A", yA, ws[0]), ("B", yB, ws[1])):
+            dg, db = torch.full((C,), 2.0, device=DEV), torch.full((C,), -1.0, device=DEV)
+            dy = torch.empty_like(dout)
+            m, i, sc, sh = st[k]
+            assert lib.icamd_bn_bwd(hip.ptr(dout), None, hip.ptr(y), hip.ptr(m), hip.ptr(i), hip.ptr(sc), hip.ptr(sh), hip.ptr(dg),
+                                    hip.ptr(db), hip.ptr(dy), None, hip.ptr(bits), rows, C, 1, accum, hip.ptr(w), wsb, s) == 0
+            ref[k] = (dy, dg, db)
+        dgA, dbA = torch.full((C,), 2.0, device=DEV), torch.full((C,), -1.0, device=DEV)
+        dgB, dbB = torch.full((C,), 2.0, device=DEV), torch.full((C,), -1.0, device=DEV)
+        dyA, dyB = torch.empty_like(dout), torch.empty_like(dout)
+        assert lib.icamd_bn_bwd_dual(hip.ptr(dout), hip.ptr(bits), hip.ptr(yA), hip.ptr(st["A"][0]), hip.ptr(st["A"][1]),
+                                     hip.ptr(st["A"][2]), hip.ptr(dgA), hip.ptr(dbA), hip.ptr(dyA), hip.ptr(yB),
+                                     hip.ptr(st["B"][0]), hip.ptr(st["B"][1]), hip.ptr(st["B"][2]), hip.ptr(dgB), hip.ptr(dbB),
+                                     hip.ptr(dyB), rows, C, accum, hip.ptr(ws[2]), hip.ptr(ws[3]), wsb, s) == 0
+        sync()
+        assert torch.equal(dyA, ref["A"][0]) and torch.equal(dyB, ref["B"][0])
+        assert torch.equal(dgA, ref["A"][1]) and torch.equal(dbA, ref["A"][2])
+        assert torch.equal(dgB, ref["B"][1]) and torch.equal(dbB, ref["B"][2])
+    # the two workspaces must be distinct
+    assert lib.icamd_bn_bwd_dual(hip.ptr(dout), hip.ptr(bits), hip.ptr(yA), hip.ptr(st["A"][0]), hip.ptr(st["A"][1]),
+                                 hip.ptr(st["A"][2]), hip.ptr(dgA), hip.ptr(dbA), hip.ptr(dyA), hip.ptr(yB), hip.ptr(st["B"][0]),
+                                 hip.ptr(st["B"][1]), hip.ptr(st["B"][2]), hip.ptr(dgB), hip.ptr(dbB), hip.ptr(dyB), rows, C, 0,
+                                 hip.ptr(ws[2]), hip.ptr(ws[2]), wsb, s) != 0
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 12, 64), (3, 9, 11, 64), (1, 16, 16, 128)])
 def test_maxpool(lib, shape):
     hip = _hip()
