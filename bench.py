@@ -256,7 +256,7 @@ def main():
         try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/)
             if args.arch != "resnet50" or B != 256:
                 raise KeyError("PMC traffic was collected for the ResNet-50 bs-256 workload only")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v3.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v4.json")))
             names = {"conv_wgrad": "conv_wgrad_kernel", "conv_fwd": "conv_igemm_kernel", "conv_dgrad": "conv_igemm_kernel"}
             sel = [v for k, v in pmc["kernels"].items() if k.startswith(names[dom])]
             n = sum(v["launches"] for v in sel)
