@@ -261,3 +261,25 @@ def test_create_optimizer_names_follow_the_reference_factory():
     for bad in ("radam", "lookahead_adamw", "fusedlamb", "rmsprop"):
         with pytest.raises(ValueError):
             OF.create_optimizer(bad, 1e-3, 0.05, m)
+
+
+def test_train_cli_surface_matches_the_reference_parser():
+    """Every flag of the reference's train.py exists here with the same default (flag table extracted from the reference
+    source by tests/golden/make_cli_fixture.py); the deliberate differences are listed."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("icamd_train_cli", os.path.join(root, "train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mine = {o: a for a in mod.get_args_parser()._actions for o in a.option_strings if o.startswith("--")}
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_cli_flags.json")))["flags"]
+    assert len(ref) >= 50
+    assert [k for k in ref if k not in mine] == []
+    deliberate = {"--model": "resnet50",      # reference default efficientvit_m0 is outside the built model families
+                  "--pretrained": False}      # no network: weights are never downloaded
+    for k, spec_ in ref.items():
+        if "default" not in spec_ or spec_["default"] == "<expr>":
+            continue
+        want = deliberate.get(k, spec_["default"])
+        assert mine[k].default == want, (k, mine[k].default, want)
+    assert sorted(k for k in mine if k not in ref and k != "--help") == ["--num_classes", "--synthetic"]
