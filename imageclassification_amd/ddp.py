@@ -4,7 +4,7 @@
 One process per GPU.  Gradients live in ONE flat fp32 arena whose order is the forward layer order, so they
 become final from the END of the arena towards the start while backward runs.  The reducer cuts the arena
 into buckets from the end (first bucket small so communication starts early, like DDP's 1 MiB first bucket,
-then 25 MiB), and as soon as backward reports that a bucket's whole range is final it enqueues
+then 25 MiB; the bucket holding the front of the arena is capped at 4 MiB because nothing overlaps its all-reduce), and as soon as backward reports that a bucket's whole range is final it enqueues
 all_reduce(SUM) for that slice on a side HIP stream (event-chained to the compute stream), overlapping the
 remaining backward kernels.  The optimizer kernel applies the 1/world averaging (grad_scale), so no extra
 pass over the gradients is needed.  xGMI note: a ring all-reduce is per-link bound; 25 MiB buckets keep each
@@ -17,14 +17,23 @@ import torch
 import torch.distributed as dist
 
 
-def make_buckets(n_elems, first_bucket_elems, bucket_elems, align=64):
-    """[(lo, hi)] covering [0, n_elems) from the END backwards; boundaries aligned to `align` elements."""
+def make_buckets(n_elems, first_bucket_elems, bucket_elems, align=64, last_bucket_elems=0):
+    """[(lo, hi)] covering [0, n_elems) from the END backwards; boundaries aligned to `align` elements.
+
+    `last_bucket_elems` > 0 caps the bucket that contains offset 0.  That bucket is launched when backward finishes, so its
+    all-reduce is the one nothing overlaps; the front of the arena (stem and first stage) holds few parameters but the
+    longest-running backward kernels, so cutting it off lets the rest of its bucket go out while they still run."""
     buckets = []
     hi = n_elems
     cap = first_bucket_elems
     while hi > 0:
         lo = max(0, hi - cap)
         lo = (lo // align) * align
+        if lo == 0 and 0 < last_bucket_elems < hi:
+            cut = (last_bucket_elems // align) * align
+            if cut > 0:
+                buckets.append((cut, hi))
+                hi = cut
         buckets.append((lo, hi))
         hi = lo
         cap = bucket_elems
@@ -35,13 +44,13 @@ class GradReducer:
     """Bucketed, overlapped all-reduce of a flat gradient tensor. Works on CUDA (RCCL, side stream) and on CPU
     tensors (gloo; used by the world_size-2 tests)."""
 
-    def __init__(self, flat_grad, first_bucket_mb=1.0, bucket_mb=25.0, process_group=None):
+    def __init__(self, flat_grad, first_bucket_mb=1.0, bucket_mb=25.0, process_group=None, last_bucket_mb=4.0):
         self.flat = flat_grad
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         esz = flat_grad.element_size()
         self.buckets = make_buckets(flat_grad.numel(), int(first_bucket_mb * (1 << 20)) // esz,
-                                    int(bucket_mb * (1 << 20)) // esz)
+                                    int(bucket_mb * (1 << 20)) // esz, last_bucket_elems=int(last_bucket_mb * (1 << 20)) // esz)
         self.on_gpu = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         self._next = 0
@@ -98,9 +107,10 @@ class GradReducer:
 class DistributedDataParallel:
     """Wrapper with DDP's surface (`.module`, call-through) for the HIP model."""
 
-    def __init__(self, module, device_ids=None, find_unused_parameters=False, first_bucket_mb=1.0, bucket_mb=25.0):
+    def __init__(self, module, device_ids=None, find_unused_parameters=False, first_bucket_mb=1.0, bucket_mb=25.0,
+                 last_bucket_mb=4.0):
         self.module = module
-        self.reducer = GradReducer(module.grad_arena, first_bucket_mb, bucket_mb)
+        self.reducer = GradReducer(module.grad_arena, first_bucket_mb, bucket_mb, last_bucket_mb=last_bucket_mb)
         module.grad_ready_hook = lambda lo, _hi=None, events=(): self.reducer.grads_ready_from(lo, events)
         # DDP constructor semantics: every rank starts from rank 0's parameters and buffers
         if dist.is_initialized() and dist.get_world_size() > 1:

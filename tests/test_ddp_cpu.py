@@ -20,6 +20,12 @@ def test_bucket_layout_covers_arena_from_the_end():
     assert (b[0][1] - b[0][0]) * 4 <= (1 << 20) + 256            # small first bucket: communication starts early
     assert all((hi - lo) * 4 <= (25 << 20) + 256 for lo, hi in b)
     assert len(b) == 5                                          # ResNet-50: 97.5 MiB -> 1 MiB + 4 x 25 MiB
+    # the bucket that holds the front of the arena (launched when backward ends: nothing overlaps it) is cut off small
+    c = make_buckets(n, (1 << 20) // 4, (25 << 20) // 4, last_bucket_elems=(4 << 20) // 4)
+    assert len(c) == 6 and c[-1] == (0, (4 << 20) // 4) and c[-2][0] == c[-1][1]
+    assert c[:4] == b[:4] and sum(hi - lo for lo, hi in c) == n
+    tiny = make_buckets(1000, 100, 300, align=1, last_bucket_elems=5000)   # cap larger than what is left: no extra cut
+    assert tiny == make_buckets(1000, 100, 300, align=1)
 
 
 def _worker(rank, world, port, q):
