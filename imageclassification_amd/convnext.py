@@ -344,7 +344,9 @@ class ConvNeXt:
                                                st.data_ptr() + 4 * rows, rows, C, LN_EPS, s), wp.name)
 
     # ------------------------------------------------------------------ forward
-    def forward_packed(self, ws):
+    def forward_packed(self, ws, logits_only=False):
+        """logits_only: a forward whose activations no backward will read (the reference's second, accuracy-only forward under
+        mixup): tensors kept only for the backward pass (the pre-GELU Mlp activations) are not written."""
         lib, s = self.lib, hip.stream_ptr()
         N, H, W = ws["N"], ws["H"], ws["W"]
         self._conv(self.stem, ws["x8"].data_ptr(), ws["s"], N, H, W, s)
@@ -368,7 +370,7 @@ class ConvNeXt:
                 self._ln(b["d"], blk["nw"], blk["nb"], b["h"], b["st"], rows, dim, s)
                 c1 = blk["fc1"]                                                   # z1 = pwconv1(h), a = gelu(z1): one kernel
                 hip.check(lib.icamd_conv2d_fwd_gelu(ctypes.byref(c1.desc(N, h, w)), b["h"].data_ptr(), self._w(c1),
-                                                    b["z1"].data_ptr(), b["a"].data_ptr(), self._pf(c1.b), s), c1.name + " + gelu")
+                                                    (None if logits_only else b["z1"].data_ptr()), b["a"].data_ptr(), self._pf(c1.b), s), c1.name + " + gelu")
                 self._conv(blk["fc2"], b["a"].data_ptr(), b["z2"], N, h, w, s)
                 keep = None
                 if self.training and blk["rate"] > 0.0:

@@ -161,7 +161,8 @@ int icamd_conv2d_stats_rows(const icamd_conv_desc* d) {
 }
 
 static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
-                         const void* addend, float* stats, int relu, void* stream, void* gelu_out = nullptr) {
+                         const void* addend, float* stats, int relu, void* stream, void* gelu_out = nullptr,
+                         int gelu_inplace = 0) {
   if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
   if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && stats == nullptr &&
@@ -169,13 +170,13 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.addend = (const bf16_t*)addend; g.bias = bias;
-    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin; g.relu = relu; g.gelu_out = (bf16_t*)gelu_out;
+    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin; g.relu = relu; g.gelu_out = (bf16_t*)gelu_out; g.gelu_inplace = gelu_inplace;
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
   }
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.in = (const bf16_t*)x; p.wt = (const bf16_t*)w; p.out = (bf16_t*)y;
-  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats; p.relu = relu; p.gelu_out = (bf16_t*)gelu_out;
+  p.addend = (const bf16_t*)addend; p.bias = bias; p.stats = stats; p.relu = relu; p.gelu_out = (bf16_t*)gelu_out; p.gelu_inplace = gelu_inplace;
   p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin;
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
   p.P = d->OH; p.Q = d->OW; p.M = d->N * d->OH * d->OW;
@@ -207,6 +208,7 @@ int icamd_conv2d_fwd_gelu(const icamd_conv_desc* d, const void* x, const void* w
                           void* stream) {
   ProfScope _prof(PC_IGEMM_FWD, stream);
   if (a == nullptr) return ICAMD_ERR_BAD_ARG;
+  if (z == nullptr) return conv_fwd_impl(d, x, w, a, bias, nullptr, nullptr, 0, stream, nullptr, /*gelu_inplace=*/1);
   return conv_fwd_impl(d, x, w, z, bias, nullptr, nullptr, 0, stream, a);
 }
 

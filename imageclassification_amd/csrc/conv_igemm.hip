@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         }
       } else {
         if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + roff[ps]));
+        if (p.gelu_inplace) o = gelu8(o);
         *(u32x4*)(p.out + roff[ps]) = o;
         if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + roff[ps]) = gelu8(o);
         if (p.stats != nullptr) {

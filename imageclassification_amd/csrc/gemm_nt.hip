@@ -206,6 +206,7 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
     if (m < p.M && co < p.N) {
       const long long off = (long long)m * p.N + co;
       if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
+      if (p.gelu_inplace) o = gelu8(o);
       *(u32x4*)(p.out + off) = o;
       if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
     }

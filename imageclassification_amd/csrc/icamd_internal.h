@@ -21,6 +21,7 @@ struct IgemmParams {
   int bnb_relu;
   int relu;              // EPI 0 only: clamp the sum at zero before rounding (inference epilogue)
   bf16_t* gelu_out;      // EPI 0, optional second output laid out like out: gelu(rounded out)   (Mlp fc1 forward)
+  int gelu_inplace;      // EPI 0: out itself receives gelu(rounded result) (forward passes that keep nothing for backward)
   const bf16_t* gelu_z;  // EPI 0, optional, laid out like out: out = rounded result * gelu'(gelu_z)  (Mlp fc2 data gradient)
   int N, IH, IW, Cin;
   int OH, OW, Cout;
@@ -46,6 +47,7 @@ struct GemmNtParams {
   int M, N, K;
   int relu;              // clamp at zero before rounding
   bf16_t* gelu_out;      // optional second output [M][N]: gelu(rounded out)
+  int gelu_inplace;      // out itself receives gelu(rounded result)
   const bf16_t* gelu_z;  // optional [M][N]: out = rounded result * gelu'(gelu_z)
   int ntiles_n;          // filled by the launcher
 };

@@ -145,7 +145,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             # reference engine.py:89-97: accuracy of the un-mixed images through the (already updated) model,
             # in train mode (BatchNorm statistics are updated a second time)
             ws2 = net.pack(samples, None)
-            logits2 = net.forward_packed(ws2)
+            logits2 = net.forward_packed(ws2, logits_only=True)   # nothing reads its saved activations
             hip.check(lib.icamd_softmax_xent(logits2.data_ptr(), net.ncls_p, B, num_classes, targets.data_ptr(), None, 1.0,
                                              0.0, 0.0, ws2["loss_rows"].data_ptr(), ws2["pred"].data_ptr(), None, s),
                       "argmax")

@@ -563,7 +563,7 @@ class ResNet:
                                             int(box[0]), int(box[1]), int(box[2]), int(box[3]), hip.stream_ptr()), "pack")
         return ws
 
-    def forward_packed(self, ws):
+    def forward_packed(self, ws, logits_only=False):   # logits_only: accepted for interface parity (BatchNorm needs every conv output)
         lib = self.lib
         s = hip.stream_ptr()
         N, H, W = ws["N"], ws["H"], ws["W"]

@@ -334,7 +334,9 @@ class VisionTransformer:
                                             None if addend is None else addend.data_ptr(), None, s), l.name)
 
     # ------------------------------------------------------------------ forward
-    def forward_packed(self, ws):
+    def forward_packed(self, ws, logits_only=False):
+        """logits_only: a forward whose activations no backward will read (the reference's second, accuracy-only forward under
+        mixup): tensors kept only for the backward pass (the pre-GELU Mlp activations) are not written."""
         lib, s = self.lib, hip.stream_ptr()
         B, M, D, T = ws["B"], ws["M"], self.dim, self.T
         hip.check(lib.icamd_conv2d_fwd(ctypes.byref(self._pe_desc(B)), ws["x8"].data_ptr(),
@@ -356,7 +358,7 @@ class VisionTransformer:
                                               b["h2"].data_ptr(), b["st2"].data_ptr(), b["st2"].data_ptr() + 4 * M, M, D, LN_EPS,
                                               s), "norm2")
             l1 = blk["fc1"]                                                       # z = fc1(h2), a = gelu(z): one kernel
-            hip.check(lib.icamd_conv2d_fwd_gelu(ctypes.byref(l1.desc(M)), b["h2"].data_ptr(), self._w(l1), b["z"].data_ptr(),
+            hip.check(lib.icamd_conv2d_fwd_gelu(ctypes.byref(l1.desc(M)), b["h2"].data_ptr(), self._w(l1), (None if logits_only else b["z"].data_ptr()),
                                                 b["a"].data_ptr(), self._pf(l1.b), s), l1.name + " + gelu")
             self._linear(blk["fc2"], b["a"], b["x2"], M, b["x1"], s)              # x2 = x1 + mlp
             x = b["x2"]

@@ -54,7 +54,9 @@ int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, voi
 int icamd_conv2d_fwd_act(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                          const void* addend, int relu, void* stream);
 /* Mlp fc1 forward with the activation fused into the store pass: z = conv(x, w) + bias rounded to bf16, a = gelu(z)
- * (exact erf GELU of the ROUNDED z: bit-identical to icamd_conv2d_fwd followed by icamd_gelu_fwd, one read of z less). */
+ * (exact erf GELU of the ROUNDED z: bit-identical to icamd_conv2d_fwd followed by icamd_gelu_fwd, one read of z less).
+ * z may be NULL for a forward pass that keeps nothing for backward (the reference's second, accuracy-only forward under
+ * mixup, engine.py:89-97): only a is written. */
 int icamd_conv2d_fwd_gelu(const icamd_conv_desc* d, const void* x, const void* w, void* z, void* a, const float* bias,
                           void* stream);
 /* Eval-mode BatchNorm (running statistics) folded into the [Cout][K] fp32 filters in front of it:

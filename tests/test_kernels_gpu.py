@@ -266,8 +266,10 @@ def test_pointwise_gelu_epilogues(lib, case):
     assert lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(x), hip.ptr(wd), hip.ptr(z1), hip.ptr(bias), None, None, s) == 0
     assert lib.icamd_gelu_fwd(hip.ptr(z1), hip.ptr(a1), z1.numel(), s) == 0
     assert lib.icamd_conv2d_fwd_gelu(ctypes.byref(d), hip.ptr(x), hip.ptr(wd), hip.ptr(z2), hip.ptr(a2), hip.ptr(bias), s) == 0
+    a3 = torch.empty_like(z1)   # z = NULL: only the activation is written (accuracy-only forward)
+    assert lib.icamd_conv2d_fwd_gelu(ctypes.byref(d), hip.ptr(x), hip.ptr(wd), None, hip.ptr(a3), hip.ptr(bias), s) == 0
     sync()
-    assert torch.equal(z1, z2) and torch.equal(a1, a2)
+    assert torch.equal(z1, z2) and torch.equal(a1, a2) and torch.equal(a1, a3)
     ref_a = R.bf16_round(torch.nn.functional.gelu(z1.float().cpu()))
     assert R.rel_l2(a2.float().cpu(), ref_a) <= 1e-3
     # backward of the layer that consumes `a`: d z = (dy W) * gelu'(z), here with this layer's shapes transposed
