@@ -47,10 +47,12 @@ int icamd_grad_norm_launch(const float* g, long long n, float inv_scale, float m
                            hipStream_t s);
 int icamd_adamw_ema_launch(float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n, float lr,
                            float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
-                           const float* clip, const int* finite_flag, int zero_grad, hipStream_t s);
+                           const float* clip, const int* finite_flag, int* skipped, int zero_grad, hipStream_t s);
 int icamd_optim_ema_launch(int kind, float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n,
                            float lr, float wd, float beta1, float beta2, float eps, int step, float gscale,
-                           float ema_decay, const float* clip, const int* finite_flag, int zero_grad, hipStream_t s);
+                           float ema_decay, const float* clip, const int* finite_flag, int* skipped, int zero_grad,
+                           hipStream_t s);
+int icamd_grad_guard_launch(float* g, long long n, const int* finite_flag, hipStream_t s);
 int icamd_lerp_launch(float* dst, const float* src, long long n, float w, const int* finite_flag, hipStream_t s);
 int icamd_bn_fold_launch(const float* w, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                          int Cout, int K, bf16_t* w_folded, float* shift, hipStream_t s);
@@ -134,7 +136,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
 
-int icamd_abi_version(void) { return 1; }
+int icamd_abi_version(void) { return 2; }
 
 int icamd_prof_enable(int on) { g_prof_on = on != 0; return ICAMD_OK; }
 int icamd_prof_classes(void) { return PC_COUNT; }
@@ -762,21 +764,27 @@ int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm
 
 int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
                     float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
-                    const int32_t* finite_flag, int zero_grad, void* stream) {
+                    const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
   if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_adamw_ema_launch(p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
-                                clip, finite_flag, zero_grad, (hipStream_t)stream);
+                                clip, finite_flag, skipped_steps, zero_grad, (hipStream_t)stream);
+}
+
+int icamd_grad_guard(float* g, long long n, const int32_t* finite_flag, void* stream) {
+  ProfScope _prof(PC_OPTIM, stream);
+  if (g == nullptr || finite_flag == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
+  return icamd_grad_guard_launch(g, n, finite_flag, (hipStream_t)stream);
 }
 
 int icamd_optim_ema(int kind, float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr,
                     float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
-                    const float* clip, const int32_t* finite_flag, int zero_grad, void* stream) {
+                    const float* clip, const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
   if (p == nullptr || g == nullptr || m == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   if ((kind == ICAMD_OPT_ADAMW || kind == ICAMD_OPT_ADAM) && v == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_optim_ema_launch(kind, p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale,
-                                ema_decay, clip, finite_flag, zero_grad, (hipStream_t)stream);
+                                ema_decay, clip, finite_flag, skipped_steps, zero_grad, (hipStream_t)stream);
 }
 
 int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream) {

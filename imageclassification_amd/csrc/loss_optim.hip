@@ -187,18 +187,42 @@ __global__ void gradnorm_finalize_kernel(const double* __restrict__ partial, int
 // skipped entirely when *finite_flag == 0 (reference: non-finite loss -> no step, engine.py:56-59)
 // ------------------------------------------------------------------------------------------------
 struct AdamArgs {
-  float lr, wd, beta1, beta2, eps, bc1, bc2_sqrt, gscale, ema_w;
+  float lr, wd, beta1, beta2, eps, gscale, ema_w;
+  int step;          // optimizer steps ATTEMPTED so far, this one included (host count)
+  int bias_correct;  // Adam family: bc1 = 1 - beta1^t, bc2 = 1 - beta2^t with t = step - *skipped (steps really taken)
 };
+
+// Steps dropped for a non-finite loss never happened as far as torch.optim's `step` state is concerned (the reference
+// `continue`s before optimizer.step(), engine.py:56-59), so the bias correction uses the device-side count of steps that
+// were really taken.  One double pow per THREAD (not per element): invisible next to 36 B/parameter of traffic.
+__device__ __forceinline__ void bias_corrections(const AdamArgs& a, const int* __restrict__ skipped, float& bc1,
+                                                 float& bc2_sqrt) {
+  bc1 = 1.f; bc2_sqrt = 1.f;
+  if (a.bias_correct) {
+    int t = a.step - (skipped != nullptr ? *skipped : 0);
+    if (t < 1) t = 1;
+    bc1 = (float)(1.0 - pow((double)a.beta1, (double)t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, (double)t));
+  }
+}
+// the skip path of every optimizer kernel: one thread counts the dropped step (nobody reads the counter in this launch)
+__device__ __forceinline__ bool step_skipped(const int* __restrict__ finite_flag, int* __restrict__ skipped) {
+  if (finite_flag == nullptr || *finite_flag != 0) return false;
+  if (skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1;
+  return true;
+}
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, float* __restrict__ ema,
                                                         bf16_t* __restrict__ shadow, long long n4, AdamArgs a,
                                                         const float* __restrict__ clip, const int* __restrict__ finite_flag,
-                                                        int zero_grad) {
-  if (finite_flag != nullptr && *finite_flag == 0) return;
+                                                        int* __restrict__ skipped, int zero_grad) {
+  if (step_skipped(finite_flag, skipped)) return;
+  float bc1, bc2_sqrt;
+  bias_corrections(a, skipped, bc1, bc2_sqrt);
   const float gs = a.gscale * (clip != nullptr ? clip[1] : 1.f);
   const float decay_mul = 1.f - a.lr * a.wd;
-  const float step_size = a.lr / a.bc1;
+  const float step_size = a.lr / bc1;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 pv = ((f32x4*)p)[i];
@@ -211,7 +235,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
       float pp = pv[e] * decay_mul;
       const float mm = mv[e] + (gg - mv[e]) * (1.f - a.beta1);
       const float v2 = vv[e] * a.beta2 + (1.f - a.beta2) * gg * gg;
-      const float denom = sqrtf(v2) / a.bc2_sqrt + a.eps;
+      const float denom = sqrtf(v2) / bc2_sqrt + a.eps;
       pp = pp - step_size * (mm / denom);
       pv[e] = pp; mv[e] = mm; vv[e] = v2;
     }
@@ -232,6 +256,16 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
       ((u32x2*)shadow)[i] = sv;
     }
   }
+}
+
+// optimizer.zero_grad() of the reference's non-finite branch (engine.py:56-59), decided on the device: the gradient arena
+// is cleared iff *finite_flag == 0 (the micro-step that just accumulated into it had a non-finite loss).  With the flag set
+// every workgroup leaves after one scalar load.
+__global__ __launch_bounds__(256) void grad_guard_kernel(float* __restrict__ g, long long n4, const int* __restrict__ finite_flag) {
+  if (*finite_flag != 0) return;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // dst += w*(src-dst)  (EMA of float buffers) ; with w == 1 a plain copy
@@ -358,15 +392,20 @@ int icamd_grad_norm_launch(const float* g, long long n, float inv_scale, float m
 
 int icamd_adamw_ema_launch(float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n, float lr,
                            float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
-                           const float* clip, const int* finite_flag, int zero_grad, hipStream_t s) {
+                           const float* clip, const int* finite_flag, int* skipped, int zero_grad, hipStream_t s) {
   if (n % 4 != 0 || step < 1) return ICAMD_ERR_BAD_ARG;
   AdamArgs a;
   a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.gscale = gscale;
-  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.step = step; a.bias_correct = 1;
   a.ema_w = 1.f - ema_decay;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, p, g, m, v, ema, shadow, n / 4, a, clip,
-                     finite_flag, zero_grad);
+                     finite_flag, skipped, zero_grad);
+  return icamd_launch_status();
+}
+
+int icamd_grad_guard_launch(float* g, long long n, const int* finite_flag, hipStream_t s) {
+  if (n % 4 != 0) return ICAMD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(grad_guard_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, g, n / 4, finite_flag);
   return icamd_launch_status();
 }
 
@@ -379,10 +418,12 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, f
                                                         float* __restrict__ v, float* __restrict__ ema,
                                                         bf16_t* __restrict__ shadow, long long n4, AdamArgs a,
                                                         const float* __restrict__ clip, const int* __restrict__ finite_flag,
-                                                        int zero_grad) {
-  if (finite_flag != nullptr && *finite_flag == 0) return;
+                                                        int* __restrict__ skipped, int zero_grad) {
+  if (step_skipped(finite_flag, skipped)) return;
+  float bc1, bc2_sqrt;
+  bias_corrections(a, skipped, bc1, bc2_sqrt);
   const float gs = a.gscale * (clip != nullptr ? clip[1] : 1.f);
-  const float step_size = a.lr / a.bc1;
+  const float step_size = a.lr / bc1;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 pv = ((f32x4*)p)[i];
@@ -397,7 +438,7 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, f
         gg += a.wd * pv[e];
         const float mm = mv[e] + (gg - mv[e]) * (1.f - a.beta1);
         const float v2 = vv[e] * a.beta2 + (1.f - a.beta2) * gg * gg;
-        pv[e] -= step_size * (mm / (sqrtf(v2) / a.bc2_sqrt + a.eps));
+        pv[e] -= step_size * (mm / (sqrtf(v2) / bc2_sqrt + a.eps));
         mv[e] = mm; vv[e] = v2;
       } else if (KIND == 2 || KIND == 3) {   // torch.optim.SGD, dampening 0; a zero buffer reproduces buf = g at step 1
         gg += a.wd * pv[e];
@@ -432,20 +473,20 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, f
 
 int icamd_optim_ema_launch(int kind, float* p, float* g, float* m, float* v, float* ema, bf16_t* shadow, long long n,
                            float lr, float wd, float beta1, float beta2, float eps, int step, float gscale,
-                           float ema_decay, const float* clip, const int* finite_flag, int zero_grad, hipStream_t s) {
+                           float ema_decay, const float* clip, const int* finite_flag, int* skipped, int zero_grad,
+                           hipStream_t s) {
   if (kind == 0) return icamd_adamw_ema_launch(p, g, m, v, ema, shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
-                                               clip, finite_flag, zero_grad, s);
+                                               clip, finite_flag, skipped, zero_grad, s);
   if (n % 4 != 0 || step < 1 || kind < 0 || kind > 4 || (kind == 1 && v == nullptr)) return ICAMD_ERR_BAD_ARG;
   AdamArgs a;
   a.lr = lr; a.wd = wd; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.gscale = gscale;
-  a.bc1 = kind == 1 ? (float)(1.0 - pow((double)beta1, (double)step)) : 1.f;
-  a.bc2_sqrt = kind == 1 ? (float)sqrt(1.0 - pow((double)beta2, (double)step)) : 1.f;
+  a.step = step; a.bias_correct = kind == 1 ? 1 : 0;
   a.ema_w = 1.f - ema_decay;
   const dim3 grid(grid_for(n / 4, 256)), block(256);
-  if (kind == 1) hipLaunchKernelGGL(optim_ema_kernel<1>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
-  else if (kind == 2) hipLaunchKernelGGL(optim_ema_kernel<2>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
-  else if (kind == 3) hipLaunchKernelGGL(optim_ema_kernel<3>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
-  else hipLaunchKernelGGL(optim_ema_kernel<4>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, zero_grad);
+  if (kind == 1) hipLaunchKernelGGL(optim_ema_kernel<1>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, skipped, zero_grad);
+  else if (kind == 2) hipLaunchKernelGGL(optim_ema_kernel<2>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, skipped, zero_grad);
+  else if (kind == 3) hipLaunchKernelGGL(optim_ema_kernel<3>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, skipped, zero_grad);
+  else hipLaunchKernelGGL(optim_ema_kernel<4>, grid, block, 0, s, p, g, m, v, ema, shadow, n / 4, a, clip, finite_flag, skipped, zero_grad);
   return icamd_launch_status();
 }
 

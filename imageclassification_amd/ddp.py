@@ -13,8 +13,72 @@ of the 7 links busy with >3 MiB chunks at 8 GPUs.
 BatchNorm buffers: DDP's per-forward broadcast of rank 0's running statistics only matters when the
 statistics are READ (evaluate / checkpoint): `sync_buffers()` does that one broadcast on demand.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+from . import hip
+
+DT_F32, DT_I32, DT_F64, DT_BF16 = 0, 1, 2, 3       # include/icamd.h ICAMD_DT_*
+RED_SUM, RED_MIN, RED_MAX = 0, 1, 2                # ICAMD_RED_*
+_DT = {torch.float32: DT_F32, torch.int32: DT_I32, torch.float64: DT_F64, torch.bfloat16: DT_BF16}
+
+
+class RcclComm:
+    """The library's own RCCL communicator (include/icamd.h `icamd_rccl_*`, csrc/collective.hip): one per process.
+    Rank 0 draws the ncclUniqueId; it travels to the other ranks over torch.distributed's control plane (the reference
+    sets that process group up in utils.py:339-375).  Collectives are enqueued through the C ABI on a caller-supplied
+    HIP stream: `icamd_allreduce_bucket_launch`, `icamd_broadcast_launch`."""
+
+    def __init__(self, rank=None, world=None, group=None):
+        self.lib = hip.load()
+        if not self.lib.icamd_rccl_available():
+            raise hip.IcamdError("librccl could not be loaded: the RCCL transport is unavailable on this host")
+        ddp_up = dist.is_available() and dist.is_initialized()
+        self.rank = (dist.get_rank(group) if ddp_up else 0) if rank is None else rank
+        self.world = (dist.get_world_size(group) if ddp_up else 1) if world is None else world
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            hip.check(self.lib.icamd_rccl_unique_id(buf), "rccl_unique_id")
+        blob = [bytes(buf.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(blob, src=0, group=group)
+        handle = ctypes.c_void_p()
+        hip.check(self.lib.icamd_rccl_comm_init(blob[0], self.world, self.rank, ctypes.byref(handle)), "rccl_comm_init")
+        self.handle = handle
+
+    def info(self):
+        """(ranks, rank) as the live communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = ctypes.c_int(0), ctypes.c_int(0)
+        hip.check(self.lib.icamd_rccl_comm_info(self.handle, ctypes.byref(n), ctypes.byref(r)), "rccl_comm_info")
+        return n.value, r.value
+
+    def all_reduce(self, t, op=RED_SUM, stream=None):
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        hip.check(self.lib.icamd_allreduce_bucket_launch(self.handle, t.data_ptr(), t.numel(), _DT[t.dtype], op, s),
+                  "allreduce_bucket_launch")
+
+    def broadcast(self, t, root=0, stream=None):
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        hip.check(self.lib.icamd_broadcast_launch(self.handle, t.data_ptr(), t.numel(), _DT[t.dtype], root, s), "broadcast_launch")
+
+    def destroy(self):
+        if self.handle is not None:
+            self.lib.icamd_rccl_comm_destroy(self.handle)
+            self.handle = None
+
+
+_default_comm = None
+
+
+def default_comm():
+    """Process-wide communicator, created on first use (after init_distributed_mode)."""
+    global _default_comm
+    if _default_comm is None:
+        _default_comm = RcclComm()
+    return _default_comm
 
 
 def make_buckets(n_elems, first_bucket_elems, bucket_elems, align=64, last_bucket_elems=0):
@@ -41,17 +105,34 @@ def make_buckets(n_elems, first_bucket_elems, bucket_elems, align=64, last_bucke
 
 
 class GradReducer:
-    """Bucketed, overlapped all-reduce of a flat gradient tensor. Works on CUDA (RCCL, side stream) and on CPU
-    tensors (gloo; used by the world_size-2 tests)."""
+    """Bucketed, overlapped all-reduce of a flat gradient tensor.
 
-    def __init__(self, flat_grad, first_bucket_mb=1.0, bucket_mb=25.0, process_group=None, last_bucket_mb=4.0):
+    Transports: "rccl" -- the library's RCCL call site (`icamd_allreduce_bucket_launch` on the side stream; default for
+    device tensors when the process group's backend is nccl, i.e. RCCL); "torch" -- torch.distributed (gloo for the CPU /
+    shared-GPU world_size-2 tests).  ICAMD_DDP_TRANSPORT overrides.  `force=True` runs the collectives at world size 1 too
+    (the single-GPU test of the real transport and of the stream / event chain)."""
+
+    def __init__(self, flat_grad, first_bucket_mb=1.0, bucket_mb=25.0, process_group=None, last_bucket_mb=4.0,
+                 transport=None, force=False, comm=None):
         self.flat = flat_grad
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = bool(force)
+        self.on_gpu = flat_grad.is_cuda
+        if transport is None:
+            transport = os.environ.get("ICAMD_DDP_TRANSPORT", "")
+        if not transport:
+            backend = dist.get_backend(process_group) if dist.is_initialized() else ("nccl" if self.on_gpu else "gloo")
+            transport = "rccl" if (self.on_gpu and backend == "nccl") else "torch"
+        if transport not in ("rccl", "torch"):
+            raise ValueError(f"unknown gradient transport {transport!r}")
+        self.transport = transport
+        self.comm = None
+        if transport == "rccl" and (self.world > 1 or self.force):
+            self.comm = comm if comm is not None else default_comm()
         esz = flat_grad.element_size()
         self.buckets = make_buckets(flat_grad.numel(), int(first_bucket_mb * (1 << 20)) // esz,
                                     int(bucket_mb * (1 << 20)) // esz, last_bucket_elems=int(last_bucket_mb * (1 << 20)) // esz)
-        self.on_gpu = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         self._next = 0
         self._works = []
@@ -65,7 +146,7 @@ class GradReducer:
     def grads_ready_from(self, lo, wait_events=()):
         """Backward reports that every gradient at offset >= lo is final once the current stream and `wait_events`
         (events of other streams that also write gradients: the weight-gradient side lane) have been reached."""
-        if self.world == 1:
+        if not self.active:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= lo:
             self._launch(self._next, wait_events)
@@ -81,19 +162,48 @@ class GradReducer:
             self.comm_stream.wait_event(ev)
             for e in wait_events:
                 self.comm_stream.wait_event(e)
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            if self.comm is not None:
+                self.comm.all_reduce(view, RED_SUM, self.comm_stream.cuda_stream)
+            else:
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
-        """Flush remaining buckets and make the compute stream wait for all reductions."""
-        if self.world == 1:
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def ranks_seen(self):
+        """Ranks in the communicator that carries the gradients (RCCL: asked of the live communicator)."""
+        if self.comm is not None:
+            return self.comm.info()[0]
+        return self.world
+
+    def finish(self, finite_flag=None):
+        """Flush remaining buckets and make the compute stream wait for all reductions.
+
+        `finite_flag` (int32 [1], 1 = this rank's loss was finite): reduced with MIN behind the last bucket, so that a
+        non-finite loss on ANY rank makes EVERY rank drop the step (the reduced gradients are poisoned for all of them) --
+        the reference has no cross-rank agreement here (engine.py:56-59: the bad rank `continue`s and the others hang in
+        their all-reduce)."""
+        if not self.active:
             return
         self.grads_ready_from(0)
         if self.on_gpu:
+            if finite_flag is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())      # the flag is written by the main stream's metrics kernel
+                self.comm_stream.wait_event(ev)
+                if self.comm is not None:
+                    self.comm.all_reduce(finite_flag, RED_MIN, self.comm_stream.cuda_stream)
+                else:
+                    with torch.cuda.stream(self.comm_stream):
+                        dist.all_reduce(finite_flag, op=dist.ReduceOp.MIN, group=self.group)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
+            if finite_flag is not None:
+                self._works.append(dist.all_reduce(finite_flag, op=dist.ReduceOp.MIN, group=self.group, async_op=True))
             for w in self._works:
                 w.wait()
         self._works = []
@@ -108,19 +218,26 @@ class DistributedDataParallel:
     """Wrapper with DDP's surface (`.module`, call-through) for the HIP model."""
 
     def __init__(self, module, device_ids=None, find_unused_parameters=False, first_bucket_mb=1.0, bucket_mb=25.0,
-                 last_bucket_mb=4.0):
+                 last_bucket_mb=4.0, transport=None, force=False):
         self.module = module
-        self.reducer = GradReducer(module.grad_arena, first_bucket_mb, bucket_mb, last_bucket_mb=last_bucket_mb)
+        self.reducer = GradReducer(module.grad_arena, first_bucket_mb, bucket_mb, last_bucket_mb=last_bucket_mb,
+                                   transport=transport, force=force)
         module.grad_ready_hook = lambda lo, _hi=None, events=(): self.reducer.grads_ready_from(lo, events)
         # DDP constructor semantics: every rank starts from rank 0's parameters and buffers
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(module.param_arena, src=0)
-            dist.broadcast(module.buffer_arena, src=0)
+        if self.reducer.active:
+            self._broadcast(module.param_arena)
+            self._broadcast(module.buffer_arena)
             module.refresh_shadow()
 
+    def _broadcast(self, t):
+        if self.reducer.comm is not None:
+            self.reducer.comm.broadcast(t, 0)      # current stream: ordered with the kernels that read the arena next
+        elif dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(t, src=0)
+
     def sync_buffers(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.broadcast(self.module.buffer_arena, src=0)
+        if self.reducer.active:
+            self._broadcast(self.module.buffer_arena)
 
     def train(self, mode=True):
         self.module.train(mode)

@@ -132,9 +132,13 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         net.grad_ready_hook = hook if is_update else None   # reduce once per optimizer step (sum of micro-steps)
         net.backward_packed(ws, accumulate=(data_iter_step % update_freq) != 0)
         net.grad_ready_hook = hook
+        if is_update and reducer is not None:
+            reducer.finish(st.finite)   # gradients summed over ranks; the finite flag becomes the MIN over ranks
+        if update_freq > 1:
+            # reference engine.py:56-59: a non-finite micro-batch zero_grad()s (dropping what the window had accumulated
+            # so far) and is skipped; decided on the device, no host sync
+            hip.check(lib.icamd_grad_guard(net.grad_arena.data_ptr(), net.n_params, st.finite.data_ptr(), s), "grad_guard")
         if is_update:
-            if reducer is not None:
-                reducer.finish()
             clip = use_amp and max_norm is not None
             if use_amp:
                 # reference utils.py:438-442: clip_grad_norm_ when clip_grad is given, else only measure the norm

@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libicamd.so")
 
+ABI_VERSION = 2
 ERRORS = {1: "ICAMD_ERR_BAD_ARG", 2: "ICAMD_ERR_UNSUPPORTED", 3: "ICAMD_ERR_WORKSPACE", 4: "ICAMD_ERR_LAUNCH"}
 
 
@@ -97,12 +98,21 @@ _SIGNATURES = {
     "icamd_grad_norm_workspace_bytes": (c_size_t, []),
     "icamd_grad_norm": (c_int, [_P, c_longlong, c_float, c_float, _P, _P, _P]),
     "icamd_adamw_ema": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float, c_int,
-                                c_float, c_float, _P, _P, c_int, _P]),
+                                c_float, c_float, _P, _P, _P, c_int, _P]),
+    "icamd_grad_guard": (c_int, [_P, c_longlong, _P, _P]),
     "icamd_optim_ema": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_longlong, c_float, c_float, c_float, c_float, c_float,
-                                c_int, c_float, c_float, _P, _P, c_int, _P]),
+                                c_int, c_float, c_float, _P, _P, _P, c_int, _P]),
     "icamd_lerp": (c_int, [_P, _P, c_longlong, c_float, _P, _P]),
     "icamd_f32_to_bf16": (c_int, [_P, _P, c_longlong, _P]),
     "icamd_colsum": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    "icamd_rccl_available": (c_int, []),
+    "icamd_rccl_version": (c_int, []),
+    "icamd_rccl_unique_id": (c_int, [_P]),
+    "icamd_rccl_comm_init": (c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    "icamd_rccl_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
+    "icamd_rccl_comm_destroy": (c_int, [_P]),
+    "icamd_allreduce_bucket_launch": (c_int, [_P, _P, c_longlong, c_int, c_int, _P]),
+    "icamd_broadcast_launch": (c_int, [_P, _P, c_longlong, c_int, c_int, _P]),
     "icamd_prof_enable": (c_int, [c_int]),
     "icamd_prof_classes": (c_int, []),
     "icamd_prof_collect": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
@@ -127,7 +137,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.icamd_abi_version() != 1:
+    if lib.icamd_abi_version() != ABI_VERSION:
         raise IcamdError("libicamd.so ABI version mismatch")
     _lib = lib
     return lib

@@ -32,7 +32,8 @@ class FusedAdamW:
         dev = model.param_arena.device
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.step_count = 0
+        self.step_count = 0       # optimizer steps ATTEMPTED (host); the device counts the ones it dropped
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         self._gn_ws = torch.empty(self.lib.icamd_grad_norm_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.norm_clip = torch.ones(2, dtype=torch.float32, device=dev)  # [grad norm, clip coefficient]
 
@@ -60,23 +61,33 @@ class FusedAdamW:
                                            float(g["lr"]), float(g["weight_decay"]), float(g["betas"][0]),
                                            float(g["betas"][1]), float(g["eps"]), self.step_count, float(grad_scale),
                                            float(decay), self.norm_clip.data_ptr() if use_clip else None,
-                                           None if finite_flag is None else finite_flag.data_ptr(), int(zero_grad),
-                                           hip.stream_ptr()), "adamw_ema")
+                                           None if finite_flag is None else finite_flag.data_ptr(),
+                                           self.skipped.data_ptr(), int(zero_grad), hip.stream_ptr()), "adamw_ema")
         m.refresh_transposed()
         if model_ema is not None:
             model_ema.after_fused_update(m, finite_flag)
+
+    @property
+    def steps_taken(self):
+        """torch.optim's `step` state: steps really applied (steps dropped for a non-finite loss do not count).  Reads the
+        device counter (one sync): checkpoint / test use only."""
+        return self.step_count - int(self.skipped.item())
+
+    def _load_step(self, step):
+        self.step_count = int(step)
+        self.skipped.zero_()
 
     def zero_grad(self, set_to_none=True):
         # gradients are overwritten (not accumulated) by the next backward unless update_freq > 1
         self.model.grad_arena.zero_()
 
     def state_dict(self):
-        return {"state": {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()},
+        return {"state": {"step": self.steps_taken, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()},
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         st = sd["state"]
-        self.step_count = int(st["step"])
+        self._load_step(st["step"])
         self.exp_avg.copy_(st["exp_avg"])
         self.exp_avg_sq.copy_(st["exp_avg_sq"])
         for g, src in zip(self.param_groups, sd["param_groups"]):
@@ -125,22 +136,22 @@ class FusedOptimizer(FusedAdamW):
                                            m.shadow.data_ptr(), m.n_params, float(g["lr"]), float(g["weight_decay"]),
                                            float(b1), float(b2), float(eps), self.step_count, float(grad_scale),
                                            float(decay), self.norm_clip.data_ptr() if use_clip else None,
-                                           None if finite_flag is None else finite_flag.data_ptr(), int(zero_grad),
-                                           hip.stream_ptr()), "optim_ema")
+                                           None if finite_flag is None else finite_flag.data_ptr(),
+                                           self.skipped.data_ptr(), int(zero_grad), hip.stream_ptr()), "optim_ema")
         m.refresh_transposed()
         if model_ema is not None:
             model_ema.after_fused_update(m, finite_flag)
 
     def state_dict(self):
         sd = super().state_dict() if self.exp_avg_sq is not None else {
-            "state": {"step": self.step_count, "exp_avg": self.exp_avg.cpu()},
+            "state": {"step": self.steps_taken, "exp_avg": self.exp_avg.cpu()},
             "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
         sd["kind"] = self.kind
         return sd
 
     def load_state_dict(self, sd):
         st = sd["state"]
-        self.step_count = int(st["step"])
+        self._load_step(st["step"])
         self.exp_avg.copy_(st["exp_avg"])
         if self.exp_avg_sq is not None:
             self.exp_avg_sq.copy_(st["exp_avg_sq"])

@@ -245,12 +245,20 @@ size_t icamd_grad_norm_workspace_bytes(void);
 /* out[0] = ||g||_2 * inv_scale ; out[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0) */
 int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm, void* workspace, float* out,
                     void* stream);
-/* torch.optim.AdamW step (decoupled wd, bias correction with `step` >= 1) on flat arenas of n (% 4 == 0)
- * floats, fused with the ModelEmaV3 lerp (ema may be NULL) and the bf16 shadow write (shadow may be NULL).
- * Gradient is scaled by gscale * clip[1] (clip may be NULL).  Skipped when *finite_flag == 0. */
+/* torch.optim.AdamW step (decoupled wd, bias correction) on flat arenas of n (% 4 == 0) floats, fused with the
+ * ModelEmaV3 lerp (ema may be NULL) and the bf16 shadow write (shadow may be NULL).
+ * Gradient is scaled by gscale * clip[1] (clip may be NULL).  Skipped when *finite_flag == 0 (reference: non-finite loss
+ * -> `continue` before optimizer.step(), engine.py:56-59).
+ * `step` >= 1 counts the steps ATTEMPTED (this one included); skipped_steps (device int32, may be NULL) counts the ones
+ * the device dropped: the kernel adds 1 to it when it skips, and the bias correction uses t = step - *skipped_steps, the
+ * number of steps really taken -- what torch.optim's `step` state would hold in the reference. */
 int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
                     float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
-                    const int32_t* finite_flag, int zero_grad, void* stream);
+                    const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream);
+/* optimizer.zero_grad() of the reference's non-finite-loss branch (engine.py:56-59) decided on the device: clears the n
+ * (% 4 == 0) gradient floats iff *finite_flag == 0.  Called after the backward of every micro-step when update_freq > 1,
+ * so a non-finite micro-batch cannot poison the gradients accumulated for the window. */
+int icamd_grad_guard(float* g, long long n, const int32_t* finite_flag, void* stream);
 /* The reference's other optimizers with a one-pass fused form (optim_factory.py:66-77), same fusion contract as
  * icamd_adamw_ema.  kind: ICAMD_OPT_ADAMW (identical to icamd_adamw_ema), ICAMD_OPT_ADAM (torch.optim.Adam, wd joins
  * the gradient), ICAMD_OPT_SGD_MOMENTUM / ICAMD_OPT_SGD_NESTEROV (torch.optim.SGD, momentum = beta1, dampening 0, wd
@@ -259,10 +267,30 @@ int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sh
 enum { ICAMD_OPT_ADAMW = 0, ICAMD_OPT_ADAM = 1, ICAMD_OPT_SGD_MOMENTUM = 2, ICAMD_OPT_SGD_NESTEROV = 3, ICAMD_OPT_LION = 4 };
 int icamd_optim_ema(int kind, float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr,
                     float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
-                    const float* clip, const int32_t* finite_flag, int zero_grad, void* stream);
+                    const float* clip, const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream);
 int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream);
 int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
 int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream);
+
+/* ---- data-parallel gradient exchange: RCCL over xGMI (replaces DistributedDataParallel's bucketed all-reduce,
+ *      /root/reference/train.py:218-222; process group /root/reference/utils.py:339-375, backend 'nccl') ------------
+ * One communicator per process (one process per GPU).  RCCL is bound lazily (dlopen): every function returns
+ * ICAMD_ERR_UNSUPPORTED where librccl is absent.  unique_id / comm_init / comm_info / comm_destroy are HOST calls
+ * (comm_init is the blocking rendezvous of ncclCommInitRank); the *_launch calls only ENQUEUE on `stream`. */
+enum { ICAMD_DT_F32 = 0, ICAMD_DT_I32 = 1, ICAMD_DT_F64 = 2, ICAMD_DT_BF16 = 3 };
+enum { ICAMD_RED_SUM = 0, ICAMD_RED_MIN = 1, ICAMD_RED_MAX = 2 };
+int icamd_rccl_available(void);                 /* 1 when librccl could be bound */
+int icamd_rccl_version(void);                   /* ncclGetVersion code, 0 when unavailable */
+int icamd_rccl_unique_id(void* id128);          /* rank 0: 128-byte rendezvous blob (HOST memory) for every rank */
+int icamd_rccl_comm_init(const void* id128, int nranks, int rank, void** comm_out);
+int icamd_rccl_comm_info(void* comm, int* nranks, int* rank);   /* ncclCommCount / ncclCommUserRank of the live communicator */
+int icamd_rccl_comm_destroy(void* comm);
+/* In-place all-reduce of one bucket (a contiguous slice of the flat gradient arena, or the int32 finite flag with
+ * ICAMD_RED_MIN) on the caller's stream: the reducer's side stream, ordered after the backward kernels that produced
+ * the slice and before the optimizer kernel by HIP events on the caller's side. */
+int icamd_allreduce_bucket_launch(void* comm, void* buf, long long count, int dtype, int op, void* stream);
+/* In-place broadcast from `root` (DDP's constructor-time parameter / buffer broadcast; BatchNorm buffers before evaluate) */
+int icamd_broadcast_launch(void* comm, void* buf, long long count, int dtype, int root, void* stream);
 
 /* ---- measurement aid (bench.py): HIP-event timing of every entry point on its launch stream ----------------
  * classes: 0 conv fwd, 1 conv dgrad, 2 conv wgrad(+slab reduce), 3 bn finalize, 4 bn apply, 5 bn bwd, 6 pooling,

@@ -44,7 +44,10 @@ def _worker(rank, world, port, q):
     for lo in (250_000, 120_000, 0):
         red.grads_ready_from(lo)
     launched_before_finish = list(red.launched)
-    red.finish()
+    # rank 1's loss was non-finite: after finish() EVERY rank sees the flag down and drops the step together
+    flag = torch.tensor([1 if rank == 0 else 0], dtype=torch.int32)
+    red.finish(flag)
+    flag_ok = int(flag.item()) == 0 and red.transport == "torch" and red.ranks_seen() == 2
     other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
     ok_sum = torch.allclose(flat, mine + other, rtol=1e-6, atol=1e-6)
     avg = flat * red.grad_scale
@@ -56,7 +59,7 @@ def _worker(rank, world, port, q):
     ml.synchronize_between_processes()
     meters_ok = (ml.meters["loss"].count == 2 and abs(ml.meters["loss"].global_avg - 1.5) < 1e-12 and
                  ml.meters["acc1"].count == 30 and abs(ml.meters["acc1"].total - (500.0 + 2000.0)) < 1e-9)
-    q.put((rank, ok_sum, ok_avg, launched_before_finish, len(red.buckets), meters_ok))
+    q.put((rank, ok_sum, ok_avg, launched_before_finish, len(red.buckets), meters_ok and flag_ok))
     dist.destroy_process_group()
 
 

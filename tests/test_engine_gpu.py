@@ -79,6 +79,44 @@ def test_non_finite_loss_skips_the_step_on_device():
     assert opt.exp_avg.abs().max().item() == 0.0
 
 
+def test_non_finite_micro_batch_under_update_freq_zeroes_the_window():
+    """update_freq=2 with an inf in the FIRST micro-batch: the reference zero_grad()s and `continue`s
+    (engine.py:56-59), so the step that closes the window applies the second micro-batch's gradient only -- and nothing
+    may become NaN.  Then an inf in the LAST micro-batch: no step at all, gradients cleared, Adam's step state untouched."""
+    C, B = 10, 8
+    _, net, opt, _ = _setup(C, seed=4)
+    from imageclassification_amd import hip
+    data = _loader(2, B, C, seed=25)
+    bad0 = (data[0][0].clone(), data[0][1])
+    bad0[0][0, 0, 0, 0] = float("inf")
+    # expected gradient: micro-batch 1 alone, scaled 1/(B*2)
+    net.train()
+    x, y = data[1]
+    ws = net.pack(x.cuda())
+    net.forward_packed(ws)
+    hip.check(net.lib.icamd_softmax_xent(ws["logits"].data_ptr(), net.ncls_p, B, C, y.cuda().data_ptr(), None, 1.0, 0.1,
+                                         1.0 / (B * 2), ws["loss_rows"].data_ptr(), ws["pred"].data_ptr(),
+                                         ws["dlogits"].data_ptr(), hip.stream_ptr()), "xent")
+    net.backward_packed(ws, accumulate=False)
+    torch.cuda.synchronize()
+    expect = net.grad_arena.clone()
+    before = net.param_arena.clone()
+    stats = _train(net, opt, [bad0, data[1]], C, update_freq=2, lr=[0.0], wd=[0.0])
+    got = net.grad_arena.clone()
+    assert torch.isfinite(got).all() and torch.isfinite(net.param_arena).all() and torch.isfinite(opt.exp_avg).all()
+    assert R.rel_l2(got.cpu(), expect.cpu()) <= 2e-2          # BN batch statistics are identical; bf16 noise only
+    assert opt.steps_taken == 1 and abs(stats["loss"]) > 0    # the window's step happened, on the finite micro-batch
+    assert torch.equal(net.param_arena, before)               # lr = 0
+    # inf in the micro-batch that closes the window: the whole step is dropped and the arena cleared
+    m_before = opt.exp_avg.clone()
+    bad1 = (data[1][0].clone(), data[1][1])
+    bad1[0][0, 0, 0, 0] = float("inf")
+    _train(net, opt, [data[0], bad1], C, update_freq=2, lr=[1e-2], wd=[0.0])
+    assert torch.equal(net.param_arena, before) and torch.equal(opt.exp_avg, m_before)
+    assert float(net.grad_arena.abs().max()) == 0.0
+    assert opt.step_count == 2 and opt.steps_taken == 1       # attempted twice, applied once (bias correction uses 1)
+
+
 def test_update_freq_accumulates_micro_batches():
     """update_freq=2: the gradient applied is d(loss_a/2 + loss_b/2) (reference engine.py:71-72)."""
     C, B = 10, 8

@@ -682,12 +682,31 @@ def test_adamw_ema_gradnorm(lib):
     p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV); ema = ema0.clone().to(DEV)
     shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
     fin = torch.ones(1, dtype=torch.int32, device=DEV)
+    skipped = torch.zeros(1, dtype=torch.int32, device=DEV)
+    attempted = 0
     for i, (gr, lr, wd) in enumerate(zip(grads, lrs, wds)):
+        if i == 2:
+            # a step dropped for a non-finite loss in the middle of the run: nothing moves, the device counts it, and the
+            # bias correction of the following steps uses the number of steps really taken (torch.optim's `step` state
+            # in the reference, whose loop `continue`s before optimizer.step(), engine.py:56-59)
+            fin.zero_()
+            attempted += 1
+            pb, mb = p.clone(), m.clone()
+            gd = torch.full((n,), float("nan"), device=DEV)
+            assert lib.icamd_adamw_ema(hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), hip.ptr(ema), hip.ptr(shadow), n, lr,
+                                       wd, 0.9, 0.999, 1e-8, attempted, 0.5, 0.9995, None, hip.ptr(fin), hip.ptr(skipped), 1,
+                                       hip.stream_ptr()) == 0
+            sync()
+            assert torch.equal(p, pb) and torch.equal(m, mb) and int(skipped.item()) == 1
+            fin.fill_(1)
+        attempted += 1
         gd = gr.clone().to(DEV)
         assert lib.icamd_adamw_ema(hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), hip.ptr(ema), hip.ptr(shadow), n, lr,
-                                   wd, 0.9, 0.999, 1e-8, i + 1, 0.5, 0.9995, None, hip.ptr(fin), 1, hip.stream_ptr()) == 0
+                                   wd, 0.9, 0.999, 1e-8, attempted, 0.5, 0.9995, None, hip.ptr(fin), hip.ptr(skipped), 1,
+                                   hip.stream_ptr()) == 0
         sync()
         assert float(gd.abs().max()) == 0.0   # zero_grad fused
+    assert int(skipped.item()) == 1
     assert torch.allclose(p.cpu(), rp, rtol=2e-5, atol=1e-6)
     assert torch.allclose(m.cpu(), rm, rtol=1e-5, atol=1e-7)
     assert torch.allclose(v.cpu(), rv, rtol=1e-5, atol=1e-9)
@@ -698,9 +717,20 @@ def test_adamw_ema_gradnorm(lib):
     pb = p.clone()
     gd = grads[0].clone().to(DEV)
     assert lib.icamd_adamw_ema(hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), hip.ptr(ema), hip.ptr(shadow), n, 1e-3,
-                               0.0, 0.9, 0.999, 1e-8, 5, 1.0, 0.9995, None, hip.ptr(fin), 1, hip.stream_ptr()) == 0
+                               0.0, 0.9, 0.999, 1e-8, 6, 1.0, 0.9995, None, hip.ptr(fin), None, 1, hip.stream_ptr()) == 0
     sync()
     assert torch.equal(p, pb)
+    # icamd_grad_guard: the arena is cleared iff the flag is down
+    gz = torch.ones(1024, device=DEV)
+    fin.fill_(1)
+    assert lib.icamd_grad_guard(hip.ptr(gz), 1024, hip.ptr(fin), hip.stream_ptr()) == 0
+    sync()
+    assert float(gz.min()) == 1.0
+    fin.zero_()
+    gz[5] = float("nan")
+    assert lib.icamd_grad_guard(hip.ptr(gz), 1024, hip.ptr(fin), hip.stream_ptr()) == 0
+    sync()
+    assert float(gz.abs().max()) == 0.0
     # grad norm + clip coefficient
     gg = torch.randn(100003, generator=g)
     ws = torch.empty(lib.icamd_grad_norm_workspace_bytes(), dtype=torch.uint8, device=DEV)
@@ -733,7 +763,7 @@ def test_other_fused_optimizers(lib, name, kind):
     for i, (gr, lr, wd) in enumerate(zip(grads, lrs, wds)):
         gd = gr.clone().to(DEV)
         assert lib.icamd_optim_ema(kind, hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), hip.ptr(ema), hip.ptr(shadow), n,
-                                   lr, wd, b1, b2, 1e-8, i + 1, 0.5, 0.9995, None, hip.ptr(fin), 1, hip.stream_ptr()) == 0
+                                   lr, wd, b1, b2, 1e-8, i + 1, 0.5, 0.9995, None, hip.ptr(fin), None, 1, hip.stream_ptr()) == 0
         sync()
         assert float(gd.abs().max()) == 0.0
     if name == "lion":
@@ -754,14 +784,14 @@ def test_other_fused_optimizers(lib, name, kind):
         pb = p0.clone().to(DEV); mb = torch.zeros(n, device=DEV); vb = torch.zeros(n, device=DEV)
         ga, gb = grads[1].clone().to(DEV), grads[1].clone().to(DEV)
         assert lib.icamd_optim_ema(0, hip.ptr(pa), hip.ptr(ga), hip.ptr(ma), hip.ptr(va), None, None, n, 1e-3, 0.05, 0.9,
-                                   0.999, 1e-8, 1, 1.0, 0.0, None, None, 0, hip.stream_ptr()) == 0
+                                   0.999, 1e-8, 1, 1.0, 0.0, None, None, None, 0, hip.stream_ptr()) == 0
         assert lib.icamd_adamw_ema(hip.ptr(pb), hip.ptr(gb), hip.ptr(mb), hip.ptr(vb), None, None, n, 1e-3, 0.05, 0.9,
-                                   0.999, 1e-8, 1, 1.0, 0.0, None, None, 0, hip.stream_ptr()) == 0
+                                   0.999, 1e-8, 1, 1.0, 0.0, None, None, None, 0, hip.stream_ptr()) == 0
         sync()
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     # bad arguments are reported, not launched
     assert lib.icamd_optim_ema(7, hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), None, None, n, 1e-3, 0.0, 0.9, 0.999,
-                               1e-8, 1, 1.0, 0.0, None, None, 0, hip.stream_ptr()) != 0
+                               1e-8, 1, 1.0, 0.0, None, None, None, 0, hip.stream_ptr()) != 0
 
 
 def test_colsum_lerp_cast(lib):
