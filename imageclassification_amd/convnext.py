@@ -26,6 +26,9 @@ CONFIGS = {
     "convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)),
     "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
     "convnext_test": ((1, 1, 2, 1), (32, 64, 128, 192)),   # small configuration for parity tests
+    # the backbone of tests/golden/convnext_ref_vectors.npz (vectors from the reference's own ConvNeXt class,
+    # /root/reference/semantic_segmentation/backbone/convnext.py:58-150)
+    "convnext_pin": ((1, 1, 1, 1), (32, 64, 96, 192)),
 }
 
 
@@ -396,7 +399,10 @@ class ConvNeXt:
         return self.forward_packed(ws)[:, : self.num_classes]
 
     # ------------------------------------------------------------------ backward
-    def backward_packed(self, ws, accumulate=False):
+    def backward_packed(self, ws, accumulate=False, dfeat=None):
+        """Backward from ws['dlogits'].  `dfeat` (bf16 NHWC tensor shaped like the last stage's output): start from that
+        gradient instead and skip the classification head -- the entry the reference-vector parity test uses, since the
+        reference tree's ConvNeXt is the headless backbone."""
         lib, s = self.lib, hip.stream_ptr()
         N = ws["N"]
         acc = int(bool(accumulate))
@@ -433,10 +439,14 @@ class ConvNeXt:
 
         dl = self.dims[-1]
         h, w = ws["final_hw"]
-        gemm_bwd(self.head, ws["pn"].data_ptr(), ws["dlogits"].data_ptr(), N, 1, 1, G[1])
-        ln_bwd(G[1], ws["pool"], ws["st_head"], self.head_nw, self.head_nb, G[2], N, dl)
         dout = G[0]
-        hip.check(lib.icamd_avgpool_bwd(G[2], W(dout), N, h * w, dl, s), "avgpool bwd")
+        if dfeat is None:
+            gemm_bwd(self.head, ws["pn"].data_ptr(), ws["dlogits"].data_ptr(), N, 1, 1, G[1])
+            ln_bwd(G[1], ws["pool"], ws["st_head"], self.head_nw, self.head_nb, G[2], N, dl)
+            hip.check(lib.icamd_avgpool_bwd(G[2], W(dout), N, h * w, dl, s), "avgpool bwd")
+        else:
+            assert dfeat.dtype == torch.bfloat16 and dfeat.numel() == N * h * w * dl
+            self._scratch(ws)[0][: dfeat.numel()].copy_(dfeat.reshape(-1))
         if hook:
             hook(self.head_nw.offset, self.n_params, lane.events())
         other = G[3]

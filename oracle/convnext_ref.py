@@ -14,7 +14,9 @@ import torch.nn.functional as F
 from .resnet_ref import _RoundBF16, _RoundWeight
 
 CONFIGS = {"convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)), "convnext_small": ((3, 3, 27, 3), (96, 192, 384, 768)),
-           "convnext_test": ((1, 1, 2, 1), (32, 64, 128, 192))}
+           "convnext_test": ((1, 1, 2, 1), (32, 64, 128, 192)),
+           # the configuration of tests/golden/convnext_ref_vectors.npz (generated from the reference's own backbone class)
+           "convnext_pin": ((1, 1, 1, 1), (32, 64, 96, 192))}
 
 
 def _r(x, on):
@@ -88,16 +90,24 @@ class ConvNeXtRef(nn.Module):
     def all_blocks(self):
         return [b for st in self.stages for b in st.blocks]
 
-    def forward(self, x):
+    def forward_features(self, x):
+        """Raw output of every stage (reference backbone: convnext.py:138-150 before its per-output norms)."""
         q = self.q
         x = _r(x, q)
         s = _r(F.conv2d(x, _w(self.stem[0].weight, q), self.stem[0].bias, stride=4), q)
         x = _r(_ln2d(s, self.stem[1]), q)
+        feats = []
         for st in self.stages:
             if not isinstance(st.downsample, nn.Identity):
                 ln = _r(_ln2d(x, st.downsample[0]), q)
                 x = _r(F.conv2d(ln, _w(st.downsample[1].weight, q), st.downsample[1].bias, stride=2), q)
             x = st.blocks(x)
+            feats.append(x)
+        return feats
+
+    def forward(self, x):
+        q = self.q
+        x = self.forward_features(x)[-1]
         pool = _r(x.mean(dim=(2, 3)), q)
         pn = _r(self.head.norm(pool), q)
         return _r(F.linear(pn, _w(self.head.fc.weight, q), self.head.fc.bias), q)

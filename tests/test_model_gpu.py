@@ -47,16 +47,83 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("arch,B,HW", [("resnet18", 8, 64), ("resnet50", 4, 64)])
-def test_forward_backward_within_oracle_reassociation_noise(arch, B, HW):
-    """bf16 training is chaotic at the rounding level: two exact-arithmetic-equivalent evaluations that sum in a
-    different order diverge by ~sqrt(depth) bf16 ulps in the activations and (through ReLU-mask flips of
-    near-zero pre-activations) by tens of percent in individual weight-gradient tensors.  The yardstick is
-    therefore the oracle against ITSELF re-associated (fp64 accumulation, same bf16 rounding points): the HIP
-    path must differ from the fp32-accumulating oracle by no more than 2x that self-noise (floors: 1e-3)."""
+def test_resnet18_forward_backward_within_asserted_reassociation_noise():
+    """ResNet-18 at timm's default init, batch 16 at 96x96.  As for ResNet-50 below: the yardstick (the oracle against its
+    own fp64-accumulating copy) is asserted small first, then the HIP path is held to 2x of it.  (Round 1's version of this
+    test used random BatchNorm weights on every layer at batch 4-8 / 64x64, where the ORACLE's own gradient noise is 0.15-1.0
+    -- ReLU-mask flips cost sqrt(fraction flipped) in relative L2 -- and so accepted anything; that configuration is now
+    only used teacher-forced, where the masks are pinned.)"""
     import copy
-    C = 10
-    ref, net = _pair(arch, C)
+    C, B, HW = 10, 16, 96
+    ref, net = _timm_default_pair("resnet18", C)
+    ref64 = copy.deepcopy(ref).double()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, HW, HW, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    ref.train(); ref64.train()
+    out = ref(x)
+    loss = torch.nn.functional.cross_entropy(out, y, label_smoothing=0.1)
+    loss.backward()
+    out64 = ref64(x.double())
+    torch.nn.functional.cross_entropy(out64, y, label_smoothing=0.1).backward()
+    net.train()
+    ws = net.pack(x.cuda())
+    logits = net.forward_packed(ws)
+    hip_loss = _xent_backward(net, ws, y.cuda(), C, smoothing=0.1)
+    got = logits[:, :C].float().cpu()
+    noise_logits = R.rel_l2(out64.detach().float(), out.detach())
+    p64 = dict(ref64.named_parameters())
+    rows = []
+    for name, p in ref.named_parameters():
+        if float(p.grad.abs().max()) == 0.0:
+            assert float(net.grad_of(name).abs().max()) == 0.0, name
+            continue
+        rows.append((name, R.rel_l2(net.grad_of(name), p.grad), R.rel_l2(p64[name].grad.float(), p.grad)))
+    mean_e = sum(r[1] for r in rows) / len(rows)
+    mean_n = sum(r[2] for r in rows) / len(rows)
+    print(f"resnet18: logits err {R.rel_l2(got, out.detach()):.2e} (self-noise {noise_logits:.2e}); mean grad err "
+          f"{mean_e:.2e} (self-noise {mean_n:.2e}) over {len(rows)} tensors")
+    assert noise_logits <= 5e-3 and mean_n <= 2e-2, (noise_logits, mean_n)
+    assert R.rel_l2(got, out.detach()) <= 2.0 * max(noise_logits, 1e-3)
+    assert abs(hip_loss - float(loss)) <= 1e-3 * abs(float(loss))
+    assert mean_e <= 2.0 * max(mean_n, 1e-3)
+    for name, e, n in rows:
+        assert e <= 3.0 * max(n, 5e-3), (name, e, n)
+
+
+def _timm_default_pair(arch, num_classes, seed=0):
+    """The configuration the reference really trains from: timm's ResNet init (Kaiming fan-out filters, BatchNorm weight 1 /
+    bias 0, ZERO-initialised last BatchNorm weight of every residual block; /root/reference/train.py:194 create_model)."""
+    from imageclassification_amd.nets import ResNet
+    torch.manual_seed(seed)
+    ref = ResNetRef(arch, num_classes, bf16_points=True, zero_init_last=True)
+    net = ResNet(arch, num_classes)
+    net.load_state_dict(ref.state_dict())
+    return ref, net
+
+
+class _As64(torch.nn.Module):
+    """fp64 copy of the oracle network fed with the same fp32 batches (the re-association yardstick)."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        return self.m(x.double())
+
+
+def test_resnet50_whole_network_parity_well_conditioned():
+    """ResNet-50 (the headline network), timm's default init, batch 32 at 128x128: every BatchNorm reduces over >= 512
+    values.  The yardstick -- the oracle against its own fp64-accumulating copy, same bf16 rounding points -- is ASSERTED to
+    be small (logits <= 5e-3, mean gradient noise <= 2e-2), so this test cannot degenerate into accepting anything; the HIP
+    path must then sit within 2x of it (floors: north_star's 1e-3 on logits / loss).  With the last BatchNorm weight of each
+    block at zero the residual branches receive an exactly-zero gradient in both implementations: asserted to be EXACTLY
+    zero on the HIP side (the branches' backward is exercised by the trajectory test below, after the first optimizer step
+    has moved those weights, and by the teacher-forced test)."""
+    import copy
+    C, B, HW = 100, 32, 128
+    ref, net = _timm_default_pair("resnet50", C)
     ref64 = copy.deepcopy(ref).double()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, 3, HW, HW, generator=g)
@@ -75,19 +142,88 @@ def test_forward_backward_within_oracle_reassociation_noise(arch, B, HW):
     hip_loss = _xent_backward(net, ws, y.cuda(), C, smoothing=0.1)
     got = logits[:, :C].float().cpu()
     noise_logits = R.rel_l2(out64.detach().float(), out.detach())
-    assert R.rel_l2(got, out.detach()) <= 2.0 * max(noise_logits, 1e-3)
-    assert abs(hip_loss - float(loss)) <= 2.0 * max(noise_logits, 1e-3) * abs(float(loss))
+    err_logits = R.rel_l2(got, out.detach())
     p64 = dict(ref64.named_parameters())
-    errs, noises = [], []
+    rows, zero_branch = [], 0
     for name, p in ref.named_parameters():
-        e = R.rel_l2(net.grad_of(name), p.grad)
-        n = R.rel_l2(p64[name].grad.float(), p.grad)
-        errs.append(e); noises.append(n)
-        assert e <= 3.0 * max(n, 2e-2), (name, e, n)
-    mean_e, mean_n = sum(errs) / len(errs), sum(noises) / len(noises)
-    print(f"{arch}: logits err {R.rel_l2(got, out.detach()):.2e} (self-noise {noise_logits:.2e}); "
-          f"mean grad err {mean_e:.2e} (self-noise {mean_n:.2e})")
-    assert mean_e <= 1.5 * max(mean_n, 1e-2)
+        if float(p.grad.abs().max()) == 0.0:
+            assert float(net.grad_of(name).abs().max()) == 0.0, name     # zero-gamma branches: exactly zero on both sides
+            zero_branch += 1
+            continue
+        rows.append((name, R.rel_l2(net.grad_of(name), p.grad), R.rel_l2(p64[name].grad.float(), p.grad)))
+    mean_e = sum(r[1] for r in rows) / len(rows)
+    mean_n = sum(r[2] for r in rows) / len(rows)
+    worst = max(rows, key=lambda r: r[1])
+    print(f"resnet50 B={B} {HW}x{HW}: logits err {err_logits:.2e} (self-noise {noise_logits:.2e}); loss {hip_loss:.6f} vs "
+          f"{float(loss):.6f}; {len(rows)} gradient tensors: mean err {mean_e:.2e} (self-noise {mean_n:.2e}), worst "
+          f"{worst[0]} {worst[1]:.2e} (its self-noise {worst[2]:.2e}); {zero_branch} zero-gradient branch tensors exact")
+    # the yardstick itself
+    assert noise_logits <= 5e-3 and mean_n <= 2e-2, (noise_logits, mean_n)
+    assert zero_branch >= 48 * 2 and len(rows) >= 40
+    # the HIP path against it
+    assert err_logits <= 2.0 * max(noise_logits, 1e-3)
+    assert abs(hip_loss - float(loss)) <= 1e-3 * abs(float(loss))
+    assert mean_e <= 2.0 * max(mean_n, 1e-3)
+    for name, e, n in rows:
+        assert e <= 3.0 * max(n, 5e-3), (name, e, n)
+
+
+def test_resnet50_loss_curve_tracks_oracle():
+    """north_star: "loss curve matching CPU reference to 1e-3".  24 optimizer steps of the reference recipe (AdamW, label
+    smoothing 0.1, lr warming up linearly from 0 as the reference's cosine_scheduler does, wd 5e-4; /root/reference/
+    engine.py:46-77) on four 32-image batches cycled, from identical timm-default weights:
+      * the CPU oracle with ITS OWN gradients (torch autograd, bf16 rounding points, torch.optim.AdamW),
+      * the same in fp64 (how far two correct implementations drift apart: the yardstick),
+      * imageclassification_amd.engine.train_one_epoch on the GPU.
+    The loss falls from 2.38 to below 1 as the batches are memorised.  Per step, the HIP loss must be within 1e-3 (relative)
+    of the oracle's wherever the oracle's own drift is below 5e-4, and within 3x that drift (floor 1e-3) everywhere; the
+    table and the step at which each pair first parts by more than 1e-3 are printed."""
+    import copy
+    from imageclassification_amd.engine import LOG_RING, train_one_epoch
+    from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
+    from imageclassification_amd.optim_factory import create_optimizer
+    from imageclassification_amd.utils import NativeScalerWithGradNormCount
+    from oracle import engine_ref as E
+    C, B, HW, steps, nb = 10, 32, 128, 24, 4
+    ref, net = _timm_default_pair("resnet50", C)
+    ref64 = copy.deepcopy(ref).double()
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(B, 3, HW, HW, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(nb)]
+    loader = [data[i % nb] for i in range(steps)]
+    lr = [1e-3 * i / steps for i in range(steps)]
+    wd = [5e-4] * steps
+
+    def oracle_run(model, params):
+        opt = torch.optim.AdamW([{"params": list(params), "weight_decay": 5e-4}], lr=1e-3, weight_decay=0.0)
+        tr = []
+        E.train_one_epoch_ref(model, E.LabelSmoothingCrossEntropyRef(0.1), [(x.clone(), t.clone()) for x, t in loader], opt,
+                              lr_schedule_values=lr, wd_schedule_values=wd, num_training_steps_per_epoch=steps,
+                              num_classes=C, trace=tr)
+        return [t["loss"] for t in tr]
+
+    l_ref = oracle_run(ref, ref.parameters())
+    l_64 = oracle_run(_As64(ref64), ref64.parameters())
+    opt = create_optimizer("adamw", 1e-3, 5e-4, net)
+    stats = train_one_epoch(net, LabelSmoothingCrossEntropy(0.1), loader, opt, torch.device("cuda"), 0,
+                            NativeScalerWithGradNormCount(), None, None, None, start_steps=0, lr_schedule_values=lr,
+                            wd_schedule_values=wd, num_training_steps_per_epoch=steps, update_freq=1, use_amp=False,
+                            num_classes=C)
+    st = list(net._step_states.values())[0]
+    l_hip = st.log[:steps].cpu().tolist()
+    d_hip = [abs(a - b) / abs(b) for a, b in zip(l_hip, l_ref)]
+    d_self = [abs(a - b) / abs(b) for a, b in zip(l_64, l_ref)]
+    print("step   oracle      oracle-fp64  HIP         |HIP-oracle|/oracle  |fp64-oracle|/oracle")
+    for i in range(steps):
+        print(f"{i:4d}   {l_ref[i]:.6f}    {l_64[i]:.6f}     {l_hip[i]:.6f}    {d_hip[i]:.2e}            {d_self[i]:.2e}")
+    part = lambda d: next((i for i, v in enumerate(d) if v > 1e-3), None)   # noqa: E731
+    print(f"first step parted by > 1e-3: HIP {part(d_hip)}, oracle fp64 {part(d_self)} (None = never in {steps} steps)")
+    assert l_ref[-1] < 0.6 * l_ref[0]                       # a real curve: the loss moved
+    assert abs(stats["loss"] - sum(l_ref) / steps) <= 1e-3 * sum(l_ref) / steps
+    assert opt.steps_taken == steps
+    for i in range(steps):
+        if d_self[i] <= 5e-4:
+            assert d_hip[i] <= 1e-3, (i, d_hip[i], d_self[i])
+        assert d_hip[i] <= 3.0 * max(d_self[i], 1e-3 / 3.0) or d_hip[i] <= 1e-3, (i, d_hip[i], d_self[i])
 
 
 @pytest.mark.parametrize("arch,B,HW,tol", [("resnet18", 8, 64, 3e-2), ("resnet50", 4, 96, 8e-2)])

@@ -283,3 +283,72 @@ def test_train_cli_surface_matches_the_reference_parser():
         want = deliberate.get(k, spec_["default"])
         assert mine[k].default == want, (k, mine[k].default, want)
     assert sorted(k for k in mine if k not in ref and k != "--help") == ["--num_classes", "--synthetic"]
+
+
+# ---- ConvNeXt oracle pinned to the reference's own definition (tests/golden/make_convnext_fixture.py) ----------------
+from _convnext_pin import _bf16_bits_to_f32, convnext_ref_to_timm_name  # noqa: E402
+
+
+def test_convnext_oracle_matches_reference_vectors():
+    """oracle/convnext_ref.py (fp32, no rounding points) against vectors computed by the reference's own Block / LayerNorm /
+    ConvNeXt classes: stage outputs, input gradient and every parameter gradient of the 4-stage backbone; single blocks at
+    dims 96 and 192 with the reference's 1e-6 layer scale; LayerNorm in both data formats."""
+    import numpy as np
+    from oracle.convnext_ref import ConvNeXtRef, _Block, _ln2d
+    from oracle import ops_ref as R
+    v = np.load(os.path.join(ROOT, "tests", "golden", "convnext_ref_vectors.npz"))
+    # backbone
+    net = ConvNeXtRef("convnext_pin", 10, bf16_points=False)
+    sd = net.state_dict()
+    names = [k[len("net/param/"):] for k in v.files if k.startswith("net/param/")]
+    assert len(names) == 4 + 3 * 4 + 4 * 9      # stem, three downsample layers, four blocks
+    for n in names:
+        t = convnext_ref_to_timm_name(n)
+        val = _bf16_bits_to_f32(v["net/param/" + n]).reshape(sd[t].shape)
+        sd[t].copy_(val)
+    x = _bf16_bits_to_f32(v["net/x"]).reshape(2, 3, 64, 64).requires_grad_(True)
+    feats = net.forward_features(x)
+    for i in range(4):
+        assert R.rel_l2(feats[i].detach(), torch.from_numpy(v[f"net/feat{i}"])) <= 2e-6, i
+    (feats[3] * torch.from_numpy(v["net/r"])).sum().backward()
+    assert R.rel_l2(x.grad, torch.from_numpy(v["net/dx"])) <= 1e-5
+    params = dict(net.named_parameters())
+    for n in names:
+        g = params[convnext_ref_to_timm_name(n)].grad
+        assert R.rel_l2(g, torch.from_numpy(v["net/grad/" + n]).reshape(g.shape)) <= 1e-5, n
+    # single blocks, layer scale 1e-6
+    for dim in (96, 192):
+        k = f"blk{dim}"
+        blk = _Block(dim, False)
+        m = {"dwconv": blk.conv_dw, "norm": blk.norm, "pwconv1": blk.mlp.fc1, "pwconv2": blk.mlp.fc2}
+        with torch.no_grad():
+            blk.gamma.copy_(_bf16_bits_to_f32(v[f"{k}/param/gamma"]))
+            for rn, mod in m.items():
+                mod.weight.copy_(_bf16_bits_to_f32(v[f"{k}/param/{rn}.weight"]).reshape(mod.weight.shape))
+                mod.bias.copy_(_bf16_bits_to_f32(v[f"{k}/param/{rn}.bias"]))
+        xb = _bf16_bits_to_f32(v[f"{k}/x"]).reshape(2, dim, 5, 7).requires_grad_(True)
+        yb = blk(xb)
+        assert R.rel_l2(yb.detach(), torch.from_numpy(v[f"{k}/y"])) <= 1e-6
+        (yb * torch.from_numpy(v[f"{k}/r"])).sum().backward()
+        assert R.rel_l2(xb.grad, torch.from_numpy(v[f"{k}/dx"])) <= 1e-6
+        assert R.rel_l2(blk.gamma.grad, torch.from_numpy(v[f"{k}/grad/gamma"])) <= 1e-5
+        for rn, mod in m.items():
+            gw = mod.weight.grad[:4] if rn.startswith("pwconv") else mod.weight.grad
+            assert R.rel_l2(gw, torch.from_numpy(v[f"{k}/grad/{rn}.weight"]).reshape(gw.shape)) <= 1e-5, (dim, rn)
+            assert R.rel_l2(mod.bias.grad, torch.from_numpy(v[f"{k}/grad/{rn}.bias"])) <= 1e-5, (dim, rn)
+    # LayerNorm: the oracle's one form (_ln2d / nn.LayerNorm over the channel axis) against BOTH reference data formats
+    C = 96
+    ln = torch.nn.LayerNorm(C, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.copy_(_bf16_bits_to_f32(v["ln/w"]))
+        ln.bias.copy_(_bf16_bits_to_f32(v["ln/b"]))
+    r = torch.from_numpy(v["ln/r"])
+    for fmt in ("channels_last", "channels_first"):
+        ln.zero_grad()
+        xl = _bf16_bits_to_f32(v["ln/x"]).reshape(2, 5, 7, C).requires_grad_(True)
+        y = ln(xl) if fmt == "channels_last" else _ln2d(xl.permute(0, 3, 1, 2), ln).permute(0, 2, 3, 1)
+        (y * r).sum().backward()
+        assert R.rel_l2(y.detach(), torch.from_numpy(v[f"ln/{fmt}/y"])) <= 1e-6
+        assert R.rel_l2(xl.grad, torch.from_numpy(v[f"ln/{fmt}/dx"])) <= 1e-5
+        assert R.rel_l2(ln.weight.grad, torch.from_numpy(v[f"ln/{fmt}/dw"])) <= 1e-5
+        assert R.rel_l2(ln.bias.grad, torch.from_numpy(v[f"ln/{fmt}/db"])) <= 1e-5
