@@ -98,6 +98,29 @@ def convnext_flops_per_image(net, hw):
     return layers
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources: PMC summaries under profiles/ are stamped with it (tools/pmc_traffic.py) so that a
+    traffic figure measured on older kernels is never reported for newer ones."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "imageclassification_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -124,7 +147,10 @@ def main():
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mixup", action="store_true", help="mixup 0.8 + cutmix 1.0 + EMA (BASELINE configs[4] recipe)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--pmc-file", default="r02_pmc_traffic.json", help="PMC traffic summary under profiles/")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches resident in HBM (SURVEY 8d: K >= 8)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,6 +195,11 @@ def main():
     else:
         net = ResNet(args.arch, C, device=str(device), seed=88)
     model = DistributedDataParallel(net) if world > 1 else net
+    # ranks in the communicator that carries the gradients, asked of the live RCCL communicator (ncclCommCount) at N > 1
+    ranks_seen = model.reducer.ranks_seen() if world > 1 else 1
+    if world > 1:
+        log(f"gradient transport: {model.reducer.transport}, communicator reports {ranks_seen} ranks, "
+            f"{len(model.reducer.buckets)} buckets")
     opt = create_optimizer("adamw", 1e-3, 5e-4, net)
     crit = LabelSmoothingCrossEntropy(0.1)
     mixup_fn, model_ema = None, None
@@ -186,7 +217,7 @@ def main():
     # synthetic pool, device resident (reference seed convention: 88 + rank, train.py:83,116)
     g = torch.Generator(device=device).manual_seed(88 + rank)
     pool = [(torch.randn(B, 3, HW, HW, generator=g, device=device),
-             torch.randint(0, C, (B,), generator=g, device=device)) for _ in range(4)]
+             torch.randint(0, C, (B,), generator=g, device=device)) for _ in range(max(1, args.pool))]
 
     def run(nsteps, start):
         loader = [pool[i % len(pool)] for i in range(nsteps)]
@@ -252,21 +283,30 @@ def main():
         dom = max(mfma_classes, key=lambda k: kern[k]["ms_per_step"])
         ach = algo[dom] / (kern[dom]["ms_per_step"] * 1e-3) / 1e12
         per_launch_flops = algo[dom] / kern[dom]["calls_per_step"]
-        traffic = None
-        try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/)
-            if args.arch != "resnet50" or B != 256:
-                raise KeyError("PMC traffic was collected for the ResNet-50 bs-256 workload only")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v4.json")))
-            names = {"conv_wgrad": "conv_wgrad_kernel", "conv_fwd": "conv_igemm_kernel", "conv_dgrad": "conv_igemm_kernel"}
-            sel = [v for k, v in pmc["kernels"].items() if k.startswith(names[dom])]
-            n = sum(v["launches"] for v in sel)
-            traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in sel) / n)
-        except Exception:
-            traffic = None
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/): only used when
+        # the summary was collected for THIS workload on THESE kernel sources (hash stamp), else null + a note
+        traffic, traffic_note = None, None
+        pmc_path = os.path.join(ROOT, "profiles", args.pmc_file)
+        try:
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload", {}).get("arch") != args.arch or pmc.get("workload", {}).get("batch") != B:
+                traffic_note = f"{args.pmc_file} was collected for another workload"
+            elif pmc.get("kernel_source_hash") != kernel_source_hash():
+                traffic_note = (f"stale: {args.pmc_file} was collected on kernel sources {pmc.get('kernel_source_hash')}, "
+                                f"this build is {kernel_source_hash()}")
+            else:
+                names = {"conv_wgrad": "conv_wgrad_kernel", "conv_fwd": "conv_igemm_kernel", "conv_dgrad": "conv_igemm_kernel"}
+                sel = [v for k, v in pmc["kernels"].items() if k.startswith(names[dom])]
+                n = sum(v["launches"] for v in sel)
+                traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in sel) / n)
+        except (OSError, KeyError, ValueError, ZeroDivisionError) as e:
+            traffic_note = f"no usable PMC summary ({type(e).__name__})"
         avg_us = round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": avg_us, "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
         lb = getattr(conv_flops_per_image, "layer_bytes", None)
         if lb is not None:
             # The same launches against the HBM roof: algorithmic bytes = each layer's input + output activations once
@@ -295,10 +335,12 @@ def main():
             ncpu = host_cores()
             log(f"cpu baseline on {ncpu} threads ...")
             with contextlib.redirect_stdout(sink):
-                ips, threads, sps = time_cpu_training(args.arch, 32, HW, C, warmup=1, steps=args.cpu_steps, threads=ncpu)
+                ips, threads, sps = time_cpu_training(args.arch, 32, HW, C, warmup=args.cpu_warmup, steps=args.cpu_steps,
+                                                      threads=ncpu)
             cpu = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
-                   "sample": f"{args.cpu_steps} steps of batch 32 (1 warm-up), torch-CPU fp32 restatement of engine.py "
-                             f"train_one_epoch, {args.arch} {HW}x{HW}, AdamW+label smoothing"}
+                   "cpu_model": cpu_model_string(),
+                   "sample": f"{args.cpu_steps} timed steps of batch 32 after {args.cpu_warmup} warm-up steps, torch-CPU fp32 "
+                             f"restatement of engine.py train_one_epoch, {args.arch} {HW}x{HW}, AdamW+label smoothing"}
         label = {"resnet50": "ResNet-50", "vit_base_patch16_224": "ViT-B/16", "convnext_tiny": "ConvNeXt-T"}.get(args.arch, args.arch)
         if args.mixup:
             label += " + mixup/cutmix + EMA"
@@ -309,7 +351,8 @@ def main():
                "config": {"workload": f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, "
                                       f"label smoothing 0.1, 1000 classes (BASELINE configs[{3 if is_vit else (4 if is_cnx else (1 if world == 1 else 2))}])",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
-               "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+               "n_ranks_seen": ranks_seen, "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+               "kernel_source_hash": kernel_source_hash(),
                "kernel_timing": {"method": "HIP events on the launch stream around every C-ABI call; separate single-stream pass "
                                            "(the timed region overlaps weight gradients on a second stream)",
                                  "steps": psteps, "ms_per_step_with_events": round(1e3 * dt_prof / psteps, 3)},

@@ -18,6 +18,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .checkpoint import PicklableModel
 from .vit import _P, _align
 
 LN_EPS = 1e-6
@@ -49,7 +50,7 @@ class _Conv:
         return d
 
 
-class ConvNeXt:
+class ConvNeXt(PicklableModel):
     def __init__(self, arch="convnext_tiny", num_classes=1000, device="cuda", drop_path_rate=0.0, seed=None):
         hip.require_gpu()
         self.lib = hip.load()
@@ -148,6 +149,9 @@ class ConvNeXt:
         self._tr_ntjobs = len(tjobs)
         self._tr_jobs = torch.tensor(jobs if jobs else [[0, 0]], dtype=torch.int32, device=dev)
         self._tr_njobs = len(jobs)
+
+    def _ctor_kwargs(self):
+        return {"arch": self.arch, "num_classes": self.num_classes, "drop_path_rate": self.drop_path_rate}
 
     def init_weights(self, seed=None):
         """timm ConvNeXt init: trunc_normal(std .02) conv / linear weights, zero biases, LayerNorm 1 / 0, gamma 1e-6."""
@@ -357,6 +361,24 @@ class ConvNeXt:
         self._ln(ws["s"], self.stem_nw, self.stem_nb, ws["x0"], ws["st_stem"], N * h * w, self.dims[0], s)
         x = ws["x0"]
         bi = 0
+        # stochastic depth (timm drop_path: per sample, scaled by 1/keep_prob): every block's mask for this step is drawn in
+        # ONE host call and uploaded ONCE from pinned memory without blocking, so the host keeps running ahead of the device
+        drop_rows = None
+        if self.training and self.injected_keep is None:
+            rates = [blk["rate"] for st in self.stages for blk in st["blocks"]]
+            if any(r > 0.0 for r in rates):
+                kp = 1.0 - torch.tensor(rates, dtype=torch.float32).view(-1, 1)
+                host = ws.get("keep_host")
+                if host is None or host.shape != (len(rates), N):
+                    host = ws["keep_host"] = torch.empty(len(rates), N, dtype=torch.float32).pin_memory()
+                    ws["keep_dev"] = torch.empty(len(rates), N, dtype=torch.float32, device=self.device)
+                if ws.get("keep_copied") is not None:
+                    ws["keep_copied"].synchronize()   # the previous step's upload (issued a whole step ago) has left `host`
+                torch.div((torch.rand(len(rates), N) < kp).float(), kp, out=host)
+                ws["keep_dev"].copy_(host, non_blocking=True)
+                ws["keep_copied"] = torch.cuda.Event()
+                ws["keep_copied"].record()
+                drop_rows = ws["keep_dev"]
         for si, (st, sw) in enumerate(zip(self.stages, ws["stages"])):
             dim = st["dim"]
             if si > 0:
@@ -380,8 +402,7 @@ class ConvNeXt:
                     if self.injected_keep is not None:
                         keep = self.injected_keep[bi].to(self.device, dtype=torch.float32)
                     else:
-                        kp = 1.0 - blk["rate"]
-                        keep = (torch.rand(N) < kp).float().div_(kp).to(self.device)   # timm drop_path: per sample, scaled
+                        keep = drop_rows[bi]
                 b["keep"] = keep
                 hip.check(lib.icamd_layerscale_fwd(b["z2"].data_ptr(), x.data_ptr(), self._pf(blk["gamma"]),
                                                    None if keep is None else keep.data_ptr(), b["out"].data_ptr(), rows, dim,

@@ -109,10 +109,12 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ih = a_ih0[j] + dh, iw = a_iw0[j] + dw;
-        // kk0 + chunk < Ktot only matters for single-tap problems whose channel count is not a multiple of 64 (ConvNeXt's
-        // 96-channel pointwise layers): the last k-step is then partly past the end of the row and reads zeros
+        // kk0 + chunk < Cin only matters for single-tap problems whose channel count is not a multiple of 64 (ConvNeXt's
+        // 96-channel pointwise layers, one parity class of a 2x2/2 data gradient): the last k-step is then partly past the
+        // end of the tap's channels and reads zeros.  (NOT Ktot: a strided data gradient's filter row holds KH*KW taps of
+        // which this launch uses one.)
         const bool ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW) &&
-                        (KMODE != 2 || kk0 + a_lc[j] < p.Ktot);
+                        (KMODE != 2 || kk0 + a_lc[j] < p.Cin);
         const bf16_t* src = ok ? in + (a_base[j] + tapoff + a_lc[j]) : zero;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * 32 + j * 8) * 128), 16, 0, 0);
       }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         bool bok = b_off[j] >= 0;
         if constexpr (KMODE == 2) {
           const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
-          bok = bok && (kk0 + ((lane & 7) ^ ((row >> 1) & 7)) * 8 < p.Ktot);
+          bok = bok && (kk0 + ((lane & 7) ^ ((row >> 1) & 7)) * 8 < p.Cin);
         }
         const bf16_t* src = bok ? wt + (b_off[j] + woff) : zero;
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);

@@ -3,10 +3,12 @@
 Boundary only: decoding and augmentation stay on the host (PIL + numpy; torchvision / timm are not available
 here), the device path starts at the fp32 NCHW batch handed to train_one_epoch.  Eval transform =
 Resize([s, s]) -> ToTensor -> Normalize(ImageNet mean/std) (datasets.py:139-144).  Train transform = the
-subset of timm.create_transform the reference configures (datasets.py:124-136: scale=(1,1), ratio=(1,1) i.e. a
-plain bicubic resize to the input size, hflip 0.5, vflip 0.5, colour jitter, pixel-mode random erasing);
-auto-augment policies (`--aa`) are not implemented and raise.
+subset of timm.create_transform the reference configures (datasets.py:124-136: RandomResizedCrop with scale=(1,1),
+ratio=(1,1) -- the whole image when it is square, timm's fallback centre crop to min(W, H) otherwise -- resized
+bicubically to the input size, hflip 0.5, vflip 0.5, colour jitter, pixel-mode random erasing); auto-augment policies
+(`--aa`) are not implemented and raise.
 """
+import json
 import os
 import random
 
@@ -98,6 +100,11 @@ class TrainTransform:
         return a
 
     def __call__(self, img):
+        W, H = img.size
+        if W != H:      # scale=(1,1), ratio=(1,1) can only be met by the fallback: a centred square of side min(W, H)
+            side = min(W, H)
+            left, top = (W - side) // 2, (H - side) // 2
+            img = img.crop((left, top, left + side, top + side))
         img = img.resize((self.size, self.size), Image.BICUBIC)
         a = np.asarray(img, dtype=np.float32) / 255.0
         if random.random() < self.hflip:
@@ -133,15 +140,26 @@ def split_dataset(dataset, train_ratio):
     by_class = {}
     for i, t in enumerate(dataset.targets):
         by_class.setdefault(t, []).append(i)
-    n_val = min(len(v) for v in by_class.values())
-    n_val = max(1, int(round(n_val * (1 - train_ratio))))
+    n_min = min(len(v) for v in by_class.values())
+    n_val = n_min - int(n_min * train_ratio)             # reference datasets.py:25
     train_idx, val_idx = [], []
     for t, idxs in sorted(by_class.items()):
         idxs = list(idxs)
         random.shuffle(idxs)
-        val_idx += idxs[:n_val]
-        train_idx += idxs[n_val:]
+        # reference datasets.py:29-30: the LAST n_val of the shuffled list validate (n_val == 0 reproduces its
+        # `indices[:-0]` / `indices[-0:]` quirk: everything validates, nothing trains)
+        train_idx += idxs[:-n_val] if n_val else []
+        val_idx += idxs[-n_val:] if n_val else idxs
     return train_idx, val_idx
+
+
+def _write_class_indices(class_to_idx, output_dir=None):
+    """./train_cls/output/class_indices.json = {index: class name} (reference datasets.py:93-97,110-114; read by the
+    reference's inference tools)."""
+    out = output_dir or os.path.join(".", "train_cls", "output")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "class_indices.json"), "w") as f:
+        f.write(json.dumps(dict((val, key) for key, val in class_to_idx.items()), indent=4))
 
 
 def build_dataset(args):
@@ -151,9 +169,13 @@ def build_dataset(args):
     if ratio == 0:
         train = ImageFolder(os.path.join(args.data_path, "train"), t_train)
         val = ImageFolder(os.path.join(args.data_path, "val"), t_val)
+        _write_class_indices(train.class_to_idx)
+        print("Number of the class = %d" % len(train.classes))
         return train, val, len(train.classes)
     base = ImageFolder(args.data_path)
     tr, va = split_dataset(base, ratio)
+    _write_class_indices(base.class_to_idx)
+    print("Number of the class = %d" % len(base.classes))
     return _Subset(base, tr, t_train), _Subset(base, va, t_val), len(base.classes)
 
 

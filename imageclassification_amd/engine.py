@@ -51,6 +51,17 @@ def _state(net, device, num_classes):
     return cache[key]
 
 
+def _criterion_smoothing(criterion):
+    """Label smoothing of whatever criterion object the caller built (reference train.py:256-261): this package's classes
+    and timm's LabelSmoothingCrossEntropy carry `.smoothing`, torch.nn.CrossEntropyLoss carries `.label_smoothing`,
+    SoftTargetCrossEntropy (mixup) carries neither -- its targets arrive already smoothed by the Mixup object."""
+    for attr in ("smoothing", "label_smoothing"):
+        v = getattr(criterion, attr, None)
+        if isinstance(v, (int, float)):
+            return float(v)
+    return 0.0
+
+
 def _unwrap(model):
     return model.module if hasattr(model, "reducer") else model
 
@@ -116,7 +127,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             smoothing, lam = mixup_fn.label_smoothing, mix[1]
             flipped = targets.flip(0).contiguous()
         else:
-            smoothing, lam, flipped = criterion.smoothing, 1.0, None
+            smoothing, lam, flipped = _criterion_smoothing(criterion), 1.0, None
         slot = steps_run % LOG_RING
         want_pred = mixup_fn is None or cheap_mixup_acc
         hip.check(lib.icamd_softmax_xent(logits.data_ptr(), net.ncls_p, B, num_classes, targets.data_ptr(),

@@ -21,6 +21,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .checkpoint import PicklableModel
 
 BN_EPS = 1e-5
 _FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
@@ -79,7 +80,7 @@ class _BN:
         self.stat_offset = None         # mean, invstd, scale, shift in the per-model stat arena (4*c floats)
 
 
-class ResNet:
+class ResNet(PicklableModel):
     """HIP ResNet. `model(x)` runs the forward and returns bf16 logits [B, num_classes] (a view)."""
 
     def __init__(self, arch="resnet50", num_classes=1000, device="cuda", zero_init_last=True, seed=None):
@@ -216,6 +217,9 @@ class ResNet:
         self._tr_ntjobs = len(tjobs)
 
     # ------------------------------------------------------------------ parameters / state_dict
+    def _ctor_kwargs(self):
+        return {"arch": self.arch, "num_classes": self.num_classes}
+
     def init_weights(self, zero_init_last=True, seed=None):
         """timm ResNet.init_weights: Kaiming-normal (fan_out, relu) convs, BN weight 1 / bias 0, zero-init of the
         last BN weight of each residual block, nn.Linear default init for the classifier."""

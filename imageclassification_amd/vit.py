@@ -19,6 +19,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
+from .checkpoint import PicklableModel
 
 LN_EPS = 1e-6
 
@@ -60,7 +61,7 @@ class _Lin:
         return d
 
 
-class VisionTransformer:
+class VisionTransformer(PicklableModel):
     def __init__(self, arch="vit_base_patch16_224", num_classes=1000, device="cuda", img_size=224, seed=None):
         hip.require_gpu()
         self.lib = hip.load()
@@ -144,6 +145,9 @@ class VisionTransformer:
         self._tr_descs = torch.tensor(descs, dtype=torch.int64, device=dev)
         self._tr_tjobs = torch.tensor(tjobs, dtype=torch.int32, device=dev)
         self._tr_ntjobs = len(tjobs)
+
+    def _ctor_kwargs(self):
+        return {"arch": self.arch, "num_classes": self.num_classes, "img_size": self.img_size}
 
     def init_weights(self, seed=None):
         """timm's default ViT init: trunc_normal(std .02) weights / pos_embed, zero biases, cls_token std 1e-6, LayerNorm

@@ -118,6 +118,7 @@ def test_hip_convnext_matches_reference_vectors():
         assert e_ref <= 1e-2, (i, e_ref)
         assert e_orc <= 2.0 * max(n_orc, 3e-3), (i, e_orc, n_orc)
     params, p64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    rows = []
     for n in names:
         t = convnext_ref_to_timm_name(n)
         g = net.grad_of(t)
@@ -126,8 +127,11 @@ def test_hip_convnext_matches_reference_vectors():
         n_orc = R.rel_l2(p64[t].grad.float(), params[t].grad)
         worst_ref = max(worst_ref, (t, e_ref), key=lambda a: a[1])
         worst_orc = max(worst_orc, (t, e_orc), key=lambda a: a[1])
-        assert e_ref <= 3e-2, (t, e_ref)
-        assert e_orc <= 2.0 * max(n_orc, 3e-3), (t, e_orc, n_orc)
+        rows.append((t, e_ref, e_orc, n_orc))
+    bad = [r_ for r_ in rows if r_[1] > 3e-2 or r_[2] > 2.0 * max(r_[3], 3e-3)]
+    for t, e_ref, e_orc, n_orc in (bad or []):
+        print(f"  {t:40s} vs reference {e_ref:.2e}  vs oracle {e_orc:.2e} (oracle self-noise {n_orc:.2e})")
+    assert not bad, [b[0] for b in bad]
     print(f"convnext_pin vs reference vectors: worst gradient rel-L2 {worst_ref[1]:.2e} at {worst_ref[0]}; vs the oracle with "
           f"bf16 rounding points {worst_orc[1]:.2e} at {worst_orc[0]}")
 

@@ -117,6 +117,18 @@ def test_non_finite_micro_batch_under_update_freq_zeroes_the_window():
     assert opt.step_count == 2 and opt.steps_taken == 1       # attempted twice, applied once (bias correction uses 1)
 
 
+def test_reference_criterion_objects_are_accepted():
+    """A caller that builds its criterion the reference's way (train.py:256-261: torch.nn.CrossEntropyLoss, or timm's
+    LabelSmoothingCrossEntropy, which carries `.smoothing`) gets the same step as with this package's criterion classes."""
+    C, B = 10, 8
+    data = _loader(1, B, C, seed=31)
+    losses = []
+    for crit in (None, torch.nn.CrossEntropyLoss(label_smoothing=0.1), torch.nn.CrossEntropyLoss()):
+        _, net, opt, _ = _setup(C, seed=6)
+        losses.append(_train(net, opt, data, C, crit=crit)["loss"])
+    assert losses[0] == losses[1] and losses[2] != losses[0]
+
+
 def test_update_freq_accumulates_micro_batches():
     """update_freq=2: the gradient applied is d(loss_a/2 + loss_b/2) (reference engine.py:71-72)."""
     C, B = 10, 8

@@ -106,6 +106,9 @@ DGRAD_CASES = [
     (2, 8, 8, 384, 96, 1, 1, 0),      # GEMM-K = 96: general path with negated taps
     (2, 9, 9, 64, 96, 3, 1, 1),       # 3x3 with Cout = 96: general path, taps straddle k-steps
     (2, 12, 12, 96, 192, 2, 2, 0),    # ConvNeXt downsample gradient: 4 parity classes of one tap each
+    (2, 8, 8, 64, 96, 2, 2, 0),       # same with Cout = 96: a single tap whose channels end mid k-step while the filter row
+                                      # goes on with the other taps (found by tests/golden/convnext_ref_vectors.npz)
+    (2, 10, 10, 128, 160, 2, 2, 0),
 ]
 
 

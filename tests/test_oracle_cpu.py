@@ -195,22 +195,40 @@ def test_optimizer_factory_surface():
         create_optimizer("lamb", 1e-3, 0.05, None)
 
 
-def test_imagefolder_split_and_eval_transform(tmp_path):
+def test_imagefolder_split_and_eval_transform(tmp_path, monkeypatch):
     """Generated 2-class ImageFolder (the reference's cat/dog set is an external download): class order, per-class
     equal validation counts (reference datasets.py:12-53) and the eval transform's arithmetic (:139-144)."""
     from types import SimpleNamespace
     from PIL import Image
     from imageclassification_amd import datasets as D
     rng = np.random.RandomState(0)
+    work = tmp_path / "work"
+    os.makedirs(work)
+    monkeypatch.chdir(work)                          # class_indices.json goes to ./train_cls/output like the reference's
+    data = tmp_path / "data"
     for cls, n in (("cat", 11), ("dog", 17)):
-        os.makedirs(tmp_path / cls)
+        os.makedirs(data / cls)
         for i in range(n):
-            Image.fromarray(rng.randint(0, 255, (20, 24, 3), dtype=np.uint8)).save(tmp_path / cls / f"{i:03d}.png")
-    args = SimpleNamespace(data_path=str(tmp_path), train_split_rato=0.8, input_size=16, color_jitter=0.3, reprob=0.25, aa="")
+            Image.fromarray(rng.randint(0, 255, (20, 24, 3), dtype=np.uint8)).save(data / cls / f"{i:03d}.png")
+    args = SimpleNamespace(data_path=str(data), train_split_rato=0.8, input_size=16, color_jitter=0.3, reprob=0.25, aa="")
     train, val, C = D.build_dataset(args)
     assert C == 2 and len(train) + len(val) == 28
     vt = [val[i][1] for i in range(len(val))]
-    assert vt.count(0) == vt.count(1) == 2          # round(11 * 0.2) = 2 of EACH class
+    assert vt.count(0) == vt.count(1) == 3          # 11 - int(11 * 0.8) = 3 of EACH class (reference datasets.py:25)
+    assert json.load(open(work / "train_cls" / "output" / "class_indices.json")) == {"0": "cat", "1": "dog"}
+    # the reference's count rule on its own example sizes: min 25, ratio 0.9 -> 25 - int(22.5) = 3 (not round(2.5) = 2)
+    fake = SimpleNamespace(targets=[0] * 25 + [1] * 40)
+    tr_i, va_i = D.split_dataset(fake, 0.9)
+    assert len(va_i) == 6 and len(tr_i) == 59 and sorted(tr_i + va_i) == list(range(65))
+    # train transform: non-square images are centre-cropped to min(W, H) before the bicubic resize (timm's
+    # RandomResizedCrop fallback for scale=(1,1), ratio=(1,1)): an image whose left/right margins are white and whose
+    # central square is black must come out all black
+    a = np.full((20, 40, 3), 255, dtype=np.uint8)
+    a[:, 10:30] = 0
+    tt = D.TrainTransform(16, color_jitter=0.0, reprob=0.0)
+    out = tt(Image.fromarray(a))
+    black = (0.0 - np.array(D.IMAGENET_DEFAULT_MEAN, dtype=np.float32)) / np.array(D.IMAGENET_DEFAULT_STD, dtype=np.float32)
+    assert np.allclose(out.numpy(), black[:, None, None] * np.ones((3, 16, 16), dtype=np.float32), atol=1e-6)
     x, y = val[0]
     assert x.shape == (3, 16, 16) and x.dtype == torch.float32
     path, _ = val.base.samples[val.indices[0]]
@@ -352,3 +370,33 @@ def test_convnext_oracle_matches_reference_vectors():
         assert R.rel_l2(xl.grad, torch.from_numpy(v[f"ln/{fmt}/dx"])) <= 1e-5
         assert R.rel_l2(ln.weight.grad, torch.from_numpy(v[f"ln/{fmt}/dw"])) <= 1e-5
         assert R.rel_l2(ln.bias.grad, torch.from_numpy(v[f"ln/{fmt}/db"])) <= 1e-5
+
+
+def test_checkpoint_model_object_serves_the_reference_consumers_without_a_gpu():
+    """checkpoint["model"] after torch.load (imageclassification_amd.checkpoint.DeferredModel): state_dict / load_state_dict /
+    eval / to / re-pickle / deepcopy work on the CPU copy -- what modelchange.py:155-162 needs with map_location="cpu" --
+    and using it as a model without a GPU fails loudly instead of computing anything on the CPU."""
+    import copy
+    import io
+    from imageclassification_amd import hip
+    from imageclassification_amd.checkpoint import DeferredModel
+    ref = ResNetRef("resnet18", 2)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    m = DeferredModel("imageclassification_amd.nets", "ResNet", {"arch": "resnet18", "num_classes": 2}, sd, True)
+    buf = io.BytesIO()
+    torch.save({"model": m, "epoch": 3}, buf)
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu", weights_only=False)
+    got = ck["model"]
+    assert isinstance(got, DeferredModel) and got.arch == "resnet18" and got.num_classes == 2 and got.training
+    assert all(torch.equal(got.state_dict()[k], sd[k]) for k in sd)
+    ema = {k: (v + 1 if v.is_floating_point() else v) for k, v in sd.items()}
+    got.load_state_dict(ema)
+    assert torch.equal(got.state_dict()["fc.weight"], sd["fc.weight"] + 1)
+    with pytest.raises(KeyError):
+        got.load_state_dict({"fc.weight": sd["fc.weight"]})
+    assert got.eval() is got and not got.training and got.to("cpu") is got
+    assert torch.equal(copy.deepcopy(got).state_dict()["conv1.weight"], got.state_dict()["conv1.weight"])
+    if not torch.cuda.is_available():
+        with pytest.raises(hip.IcamdError):
+            got(torch.zeros(1, 3, 32, 32))

@@ -49,6 +49,29 @@ def test_train_cli_two_class_imagefolder(tmp_path, monkeypatch):
     sd = ck["model"].state_dict()                                   # the reference's consumers call exactly this
     assert sd["conv1.weight"].shape == (64, 3, 7, 7) and sd["fc.weight"].shape == (2, 512)
     assert os.path.exists(work / "train_cls" / "output" / "checkpoint-best.pth")
+    # checkpoint["model"] is usable the way the reference's tools use it:
+    #  * modelchange.py:155-162 convert_model_ema_to_model: load on the CPU, model.load_state_dict(model_ema), re-save
+    best = work / "train_cls" / "output" / "checkpoint-best.pth"
+    conv = work / "train_cls" / "output" / "checkpoint-best-converted.pth"
+    c = torch.load(best, map_location="cpu", weights_only=False)
+    c["model"].load_state_dict(c["model_ema"])
+    c.pop("model_ema", None); c.pop("optimizer", None); c.pop("scaler", None)
+    torch.save(c, conv)
+    c2 = torch.load(conv, map_location="cpu", weights_only=False)
+    ema_sd = torch.load(best, map_location="cpu", weights_only=False)["model_ema"]
+    assert all(torch.equal(c2["model"].state_dict()[k], ema_sd[k]) for k in ema_sd if ema_sd[k].is_floating_point())
+    #  * val.py:14-28 initialize_model + inference: model = checkpoint["model"]; model.eval(); model(img)
+    model = c2["model"]
+    model.to(torch.device("cuda")).eval()
+    from PIL import Image
+    from imageclassification_amd.datasets import build_transform
+    img = build_transform(False, args)(Image.open(data / "dog" / "000.png").convert("RGB")).unsqueeze(0)
+    with torch.no_grad():
+        out = model(img.to("cuda"))
+    assert tuple(out.shape) == (1, 2) and int(out.float().argmax(1)) == 1        # class index 1 = "dog"
+    import copy
+    clone = copy.deepcopy(model)                                                   # timm ModelEmaV3(model) deep-copies it
+    assert torch.equal(clone.state_dict()["fc.weight"], model.state_dict()["fc.weight"])
     # auto-resume continues from the latest numbered checkpoint with optimizer state
     args2 = T.get_args_parser().parse_args(argv[:-6] + ["--epochs", "4", "--use_amp", "true", "--reprob", "0"])
     args2.epochs = 4

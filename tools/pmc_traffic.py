@@ -3,11 +3,17 @@ MI355X_MICROARCH.md prescribes: the two do not fit one TCC pass) of the same ben
 derived counters in KiB; on gfx950 FETCH_SIZE additionally counts 128 B requests as 64 B, so it is doubled (guide, HBM
 section).  Sanity anchor: the BatchNorm kernels' result must equal their algorithmic bytes (profiles/README.md).
 
-Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <steps_in_run> <out.json>"""
+The summary is stamped with the workload and with bench.kernel_source_hash() of the tree it is run from (run it from the
+snapshot that was profiled): bench.py reports `roofline.traffic` from it only while both match.
+
+Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <steps_in_run> <out.json> [arch] [batch]"""
 import json
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(db_path, counter):
@@ -29,6 +35,9 @@ def per_kernel(db_path, counter):
 
 def main():
     fetch_db, write_db, steps, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    arch = sys.argv[5] if len(sys.argv) > 5 else "resnet50"
+    batch = int(sys.argv[6]) if len(sys.argv) > 6 else 256
+    from bench import kernel_source_hash
     # units: rocprofv3's derived FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 correction x2 on FETCH_SIZE (guide, HBM section)
     fetch = per_kernel(fetch_db, "FETCH_SIZE")
     write = per_kernel(write_db, "WRITE_SIZE")
@@ -47,6 +56,7 @@ def main():
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) via tools/pmc_traffic.py; %d steps in the "
                      "profiled run; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
                      "bytes" % steps,
+           "workload": {"arch": arch, "batch": batch}, "kernel_source_hash": kernel_source_hash(),
            "kernels": kernels, "total_fetch_GB_per_step": tf, "total_write_GB_per_step": tw}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
