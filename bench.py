@@ -37,7 +37,7 @@ def conv_flops_per_image(net, hw):
         ow = (iw + 2 * conv.pad - conv.k) // conv.stride + 1
         layers.append((conv.name, 2 * oh * ow * conv.cout * conv.cin * conv.k * conv.k))
         # algorithmic HBM bytes: bf16 input (stem: RGB stored zero-padded to 8 channels), bf16 output, filter elements
-        cin_mem = max(conv.cin, 8)
+        cin_mem = getattr(conv, "cin_p", max(conv.cin, 8))   # channels as stored (stem: rgb4 layout)
         layer_bytes.append((2 * ih * iw * cin_mem, 2 * oh * ow * conv.cout, conv.cout * cin_mem * conv.k * conv.k))
         return oh, ow
 

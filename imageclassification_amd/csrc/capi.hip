@@ -5,7 +5,6 @@
 #include <string.h>
 
 // launchers defined in the kernel translation units
-int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream);
 int icamd_bn_finalize_launch(const float* part, int nrows, int C, double count, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, float* mean,
                              float* invstd, float* scale, float* shift, double* chunks, hipStream_t s);
@@ -37,6 +36,8 @@ int icamd_avgpool_fwd_launch(const bf16_t* x, bf16_t* out, int N, int HW, int C,
 int icamd_avgpool_bwd_launch(const bf16_t* dout, bf16_t* dx, int N, int HW, int C, hipStream_t s);
 int icamd_pack_input_launch(const float* x, bf16_t* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                             int xl, int xh, hipStream_t s);
+int icamd_pack_input_rgb4_launch(const float* x, bf16_t* out, int B, int Cin, int H, int W, int mode, float lam, int yl,
+                                 int yh, int xl, int xh, hipStream_t s);
 int icamd_softmax_xent_launch(const bf16_t* logits, int ld, int B, int C, const long long* y1, const long long* y2,
                               float lam, float smoothing, float gscale, float* loss_rows, int* pred, bf16_t* dlogits,
                               hipStream_t s);
@@ -732,6 +733,70 @@ int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, in
   if (x == nullptr || out == nullptr || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return ICAMD_ERR_BAD_ARG;
   if (mode != 0 && (B % 2) != 0) return ICAMD_ERR_BAD_ARG;  // timm Mixup asserts an even batch
   return icamd_pack_input_launch(x, (bf16_t*)out, B, Cin, H, W, mode, lam, yl, yh, xl, xh, (hipStream_t)stream);
+}
+
+int icamd_pack_input_rgb4(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                          int xl, int xh, void* stream) {
+  ProfScope _prof(PC_PACK, stream);
+  if (x == nullptr || out == nullptr || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return ICAMD_ERR_BAD_ARG;
+  return icamd_pack_input_rgb4_launch(x, (bf16_t*)out, B, Cin, H, W, mode, lam, yl, yh, xl, xh, (hipStream_t)stream);
+}
+
+// ---- ResNet stem: 7x7 stride 2 pad 3 convolution on the rgb4 layout ------------------------------------------------
+static bool stem_shape_ok(int N, int H, int W, int Cout) {
+  return N > 0 && H >= 7 && W >= 8 && W % 2 == 0 && Cout > 0 && Cout % 8 == 0 && (long long)N * H * (W + 8) * 4 < (1ll << 31);
+}
+
+int icamd_stem7x7s2_stats_rows(int N, int H, int W) {
+  const long long M = (long long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+  return (int)((M + 127) / 128);
+}
+
+int icamd_stem7x7s2_fwd(const void* x4, const void* w, void* y, const float* bias, float* stats, int relu, int N, int H,
+                        int W, int Cout, void* stream) {
+  ProfScope _prof(PC_IGEMM_FWD, stream);
+  if (x4 == nullptr || w == nullptr || y == nullptr || !stem_shape_ok(N, H, W, Cout)) return ICAMD_ERR_BAD_ARG;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;   // (H + 6 - 7) / 2 + 1
+  if ((long long)N * OH * OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = (const bf16_t*)x4; p.wt = (const bf16_t*)w; p.out = (bf16_t*)y; p.bias = bias; p.stats = stats; p.relu = relu;
+  p.N = N; p.IH = H; p.IW = W + 8; p.Cin = 4;              // IW: padded row pitch in pixels; Cin: elements per pixel
+  p.OH = OH; p.OW = OW; p.Cout = Cout;
+  p.P = OH; p.Q = OW; p.M = N * OH * OW;
+  p.ostr = 1; p.istr = 2;
+  p.ntaps = 1; p.Ktot = 256; p.KW = 1; p.tap_sign = 1; p.regular_taps = 1;
+  p.stem7 = 1;
+  return icamd_igemm_launch(p, (hipStream_t)stream);
+}
+
+size_t icamd_stem7x7s2_wgrad_workspace_bytes(int N, int H, int W, int Cout) {
+  if (!stem_shape_ok(N, H, W, Cout)) return 0;
+  const long long M = (long long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+  if (M >= (1ll << 30)) return 0;
+  int S = 1, rows = 0;
+  icamd_wgrad_plan((int)M, Cout, 256, &S, &rows);
+  return (size_t)S * Cout * (256 + 1) * sizeof(float);
+}
+
+int icamd_stem7x7s2_wgrad(const void* x4, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                          int N, int H, int W, int Cout, void* stream) {
+  ProfScope _prof(PC_WGRAD, stream);
+  if (x4 == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
+  const size_t need = icamd_stem7x7s2_wgrad_workspace_bytes(N, H, W, Cout);
+  if (need == 0) return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)x4; p.dy = (const bf16_t*)dy; p.slab = (float*)workspace;
+  p.N = N; p.IH = H; p.IW = W + 8; p.Cin = 4; p.OH = (H - 1) / 2 + 1; p.OW = (W - 1) / 2 + 1; p.Cout = Cout;
+  p.KH = 8; p.KW = 8; p.stride = 2; p.pad = 3;
+  p.M = N * p.OH * p.OW; p.Ktot = 256;
+  p.stem7 = 1;
+  icamd_wgrad_plan(p.M, p.Cout, p.Ktot, &p.S, &p.rows_per_split);
+  int rc = icamd_wgrad_launch(p, (hipStream_t)stream);
+  if (rc) return rc;
+  return icamd_slab_reduce_launch(p.slab, dw, (long long)p.Cout * p.Ktot, p.S, accumulate, (hipStream_t)stream, 1);
 }
 
 int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* y1, const int64_t* y2, float lam,

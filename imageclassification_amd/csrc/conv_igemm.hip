@@ -31,6 +31,11 @@ constexpr int BK = 64;
 // EPI 0: out = [relu](acc (+bias)(+addend)); optional statistics of the rounded outputs (BatchNorm forward).
 // EPI 1: data-gradient with the next BatchNorm-backward fused in: g = (acc + addend) * [ReLU mask], out = g, and the
 //        partial rows hold sum(g) and sum(g * xhat), xhat from the BN input `bnb_y` (BatchNorm backward, pass 1).
+// KMODE 3: the ResNet stem (7x7 stride 2 pad 3 on the [N][H][W+8][4] layout of icamd_pack_input_rgb4): the reduction is
+//          8 kernel rows x (8 pixels x 4 channels) = 256 with zero filter entries for row 7, pixel 7 and channel 3; a 64-wide
+//          k-step is two kernel rows, each one contiguous 64 B piece of the padded image -- no per-chunk tap arithmetic, no
+//          border case along W (1.74x the algorithmic MFMA work instead of 2.67x for the 8-channel general path, half the
+//          input bytes, and the gather costs two adds per load).
 template <int BN, int KMODE, int EPI>   // KMODE 0: uniform taps; 1: per-chunk taps; 2: single tap with a partial last k-step
 __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) : 2)) void conv_igemm_kernel(const IgemmParams p) {
   constexpr int NSTAGE = ICAMD_IGEMM_STAGES;
@@ -98,7 +103,21 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
   auto stage = [&](int ks, int buf) {
     unsigned char* sA = smem + buf * STAGE_BYTES;
     unsigned char* sB = sA + A_BYTES;
-    if constexpr (KMODE != 1) {
+    if constexpr (KMODE == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 2 * ks + (a_lc[j] >> 5);                    // kernel row of this lane's chunk
+        const int ih = a_ih0[j] - 3 + r;
+        const bool ok = r < 7 && (unsigned)ih < (unsigned)p.IH;   // a_ih0 is hugely negative for rows past M
+        const bf16_t* src = ok ? in + (a_base[j] + (r - 3) * p.IW * 4 + (a_lc[j] & 31)) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * 32 + j * 8) * 128), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) {
+        const bf16_t* src = b_off[j] >= 0 ? wt + (b_off[j] + ks * BK) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + (wave * (BN / 4) + j * 8) * 128), 16, 0, 0);
+      }
+    } else if constexpr (KMODE != 1) {
       // all 64 k of this step share one tap (Cin % 64 == 0, or a single tap): tap index and channel offset are wave-uniform
       const int kk0 = ks * BK;
       const int t = kk0 / p.Cin;          // uniform
@@ -414,8 +433,8 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   if (p.Cout % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   // "general" path: per-chunk taps (the 8-channel stem, ConvNeXt's 2x2 downsample at 96 channels, ...).  Single-tap
   // problems stay on the uniform-tap path whatever their channel count: a k-step cannot straddle taps there.
-  const bool cin8 = (p.Cin % 64 != 0) && p.ntaps != 1;
-  if (p.Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
+  const bool cin8 = !p.stem7 && (p.Cin % 64 != 0) && p.ntaps != 1;
+  if (!p.stem7 && p.Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if (cin8 && !p.regular_taps) return ICAMD_ERR_UNSUPPORTED;   // strided data gradients need Cout % 64 == 0
   if (cin8 && p.Ktot != p.ntaps * p.Cin) return ICAMD_ERR_BAD_ARG;
   if ((long long)p.N * p.IH * p.IW * p.Cin >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
@@ -435,6 +454,10 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
     if (p.bnb_relu && p.bnb_mask == nullptr && (p.bnb_scale == nullptr || p.bnb_shift == nullptr)) return ICAMD_ERR_BAD_ARG;
     if (p.Cin % 64 != 0) return ICAMD_ERR_UNSUPPORTED;
     return bn == 64 ? launch<64, 0, 1>(p, stream) : launch<128, 0, 1>(p, stream);
+  }
+  if (p.stem7) {   // set up by icamd_stem7x7s2_fwd: Cin = 4, IW = padded row pitch, istr = 2, Ktot = 256, 4 k-steps
+    p.ksteps = 4;
+    return bn == 64 ? launch<64, 3, 0>(p, stream) : launch<128, 3, 0>(p, stream);
   }
   const bool tail = !cin8 && (p.Cin % 64 != 0);   // single tap, channel count not a multiple of the k-step
   if (bn == 64) return cin8 ? launch<64, 1, 0>(p, stream) : (tail ? launch<64, 2, 0>(p, stream) : launch<64, 0, 0>(p, stream));

@@ -21,7 +21,7 @@ constexpr int BKR = 64;  // reduction rows (pixels) per stage
 
 template <int W>  // W = tile row width in elements (64 or 128)
 __device__ __forceinline__ int tr_swz(int row) {
-  if constexpr (W == 128) return (row & 3) | (((row >> 3) & 1) << 2);
+  if constexpr (W >= 128) return (row & 3) | (((row >> 3) & 1) << 2);   // 256-wide rows: same key on the low 3 block bits
   else return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
 }
 
@@ -82,7 +82,14 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
     const int lc = pc ^ (tr_swz<BMK>(row) << 1);
     const int kk = k0 + lc * 8;
     x_row[j] = row;
-    if (kk < p.Ktot) {
+    if (p.stem7) {
+      // k = row*32 + pixel*4 + channel over the [N][H][W+8][4] image: a 16 B chunk is two pixels of one kernel row; row 7
+      // does not exist (zero page), pixel 7's gradient is cleared by the slab reducer
+      const int r = kk >> 5;
+      x_ci[j] = (kk < p.Ktot && r < 7) ? 0 : -1;
+      x_dh[j] = r - 3;
+      x_dw[j] = (kk & 31) >> 2;
+    } else if (kk < p.Ktot) {
       const unsigned int t = fdiv((unsigned)kk, p.divCin);
       const unsigned int r = fdiv(t, p.divKW);
       x_ci[j] = kk - t * p.Cin;
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
         const unsigned int oh = fdiv(rem, p.divW);
         const unsigned int ow = rem - oh * p.OW;
         const int ih = (int)oh * p.stride + x_dh[j], iw = (int)ow * p.stride + x_dw[j];
+        // stem7: IW is the padded pitch and iw a padded column (always inside the row)
         if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
           src = x + (((n * p.IH + ih) * p.IW + iw) * p.Cin + x_ci[j]);
       }
@@ -218,12 +226,251 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Ring-pipelined form of the same kernel (the default): the pixel reduction is walked in 32-row stages through a ring of
+// NSLOT LDS slots that LDS-DMA fills NSLOT-1 stages ahead.  A wave waits only for ITS OWN loads of the stage it is about
+// to read (counted s_waitcnt vmcnt: the younger stages stay in flight across the barrier), one raw s_barrier per stage
+// both publishes that stage and frees the slot read one stage earlier, which is refilled at once.  All LDS lives in one
+// array and the loop contains no register-destination global load, so the compiler never drains the DMA queue
+// (cdna_hip_programming.md, "Pipelining across barriers").  The single-stage kernel above exposed the full L2/HBM latency
+// of every 64-row step behind a block-wide barrier (19.8 % MFMA-busy on MI355X, profiles/r01_pmc_mfma_busy.json).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RKR = 32;   // reduction rows (pixels) per ring stage
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `younger` whole stages (LPW LDS-DMA instructions each) of this wave are still in flight
+template <int LPW> __device__ __forceinline__ void ring_wait(int younger) {
+  if (younger >= 3) wait_vmcnt<3 * LPW>();
+  else if (younger == 2) wait_vmcnt<2 * LPW>();
+  else if (younger == 1) wait_vmcnt<LPW>();
+  else wait_vmcnt<0>();
+}
+
+// ds_read_b64_tr_b16 through inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the BUILTIN form of this read
+// whenever an LDS-DMA is in flight (it cannot tell the slots apart), which would drain the ring every stage.  The asm
+// form is invisible to that pass; its completion is waited for by hand (lgkmcnt(0) + sched_barrier, cdna_hip_programming.md
+// 5.7 / rule 18).  EXEC is all ones everywhere these are issued (no divergent control flow in the main loop).
+__device__ __forceinline__ bf16x8 tr_read_pair_asm(unsigned a0, unsigned a1) {
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// Tile shapes.  Measured on MI355X (profiles/README.md, round 2): every deep layer of ResNet-50 ran the 128x128-tile
+// kernel at the SAME rate of LDS-DMA traffic, 8.8-8.9 TB/s (L2 -> LDS; each operand row is re-read once per tile of the
+// other operand), whatever the pipelining -- i.e. the kernel's roof is that path, and its arithmetic intensity against it
+// is 2*BMK*BNC*32 flop per (BMK+BNC)*64 staged bytes = 64 flop/B for 128x128 (-> ~570 TFLOP/s), 85 for 256x128, 128 for
+// 256x256.  The ring kernel is therefore built for larger output tiles: WK x WC waves, each owning a
+// (BMK/WK) x (BNC/WC) sub-tile of 128x64 or 64x64 accumulators.
+template <int BMK, int BNC, int WK, int WC, int NSLOT, int WPS>
+__global__ __launch_bounds__(64 * WK * WC, WPS) void conv_wgrad_ring_kernel(const WgradParams p) {
+  constexpr int NW = WK * WC;                           // waves per workgroup
+  constexpr int X_BYTES = RKR * BMK * 2;
+  constexpr int Y_BYTES = RKR * BNC * 2;
+  constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
+  constexpr int XROWB = BMK * 2, YROWB = BNC * 2;
+  constexpr int XCPR = BMK / 8, YCPR = BNC / 8;        // 16 B chunks per row
+  constexpr int XRPI = (64 / XCPR) > 0 ? (64 / XCPR) : 1, YRPI = (64 / YCPR) > 0 ? (64 / YCPR) : 1;   // rows per wave-instruction
+  static_assert(XCPR <= 64 && YCPR <= 64, "a row must not exceed one wave-instruction (1 KiB)");
+  constexpr int XJ = BMK / 16 / NW, YJ = BNC / 16 / NW;   // LDS-DMA instructions per wave and stage
+  static_assert(XJ >= 1 && YJ >= 1 && XJ * NW * 16 == BMK && YJ * NW * 16 == BNC, "staging split");
+  constexpr int LPW = XJ + YJ;
+  constexpr int KR = BMK / WK / 16, CR = BNC / WC / 16;   // 16-wide fragments per wave (kk, co)
+  constexpr int KH2 = KR / 2;                              // the MFMA block is issued in two halves (see below)
+  static_assert(NSLOT >= 2 && NSLOT <= 5 && KR % 2 == 0, "ring depth / fragment split");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSLOT * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA destinations stay scalar
+  const int wk = wave % WK, wc = wave / WK;
+
+  // block order: see conv_wgrad_kernel (all tiles of one pixel split on one XCD)
+  const unsigned int nt = (unsigned)(p.ntiles_k * p.ntiles_c);
+  const unsigned int grp = blockIdx.x / (8u * nt);
+  const unsigned int rem = blockIdx.x - grp * 8u * nt;
+  const unsigned int ns = min(8u, (unsigned)p.S - grp * 8u);
+  const unsigned int tile = rem / ns;
+  const int split = (int)(grp * 8u + (rem - tile * ns));
+  const int tile_c = (int)(tile % (unsigned)p.ntiles_c);
+  const int tile_k = (int)(tile / (unsigned)p.ntiles_c);
+  const int k0 = tile_k * BMK, c0 = tile_c * BNC;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+  const bf16_t* __restrict__ x = p.x;
+  const bf16_t* __restrict__ dy = p.dy;
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+
+  int x_row[XJ], x_dh[XJ], x_dw[XJ], x_ci[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int row = (wave * XJ + j) * XRPI + lane / XCPR;
+    const int pc = lane % XCPR;
+    const int lc = pc ^ (tr_swz<BMK>(row) << 1);
+    const int kk = k0 + lc * 8;
+    x_row[j] = row;
+    if (p.stem7) {
+      // k = row*32 + pixel*4 + channel over the [N][H][W+8][4] image: a 16 B chunk is two pixels of one kernel row; row 7
+      // does not exist (zero page), pixel 7's gradient is cleared by the slab reducer
+      const int r = kk >> 5;
+      x_ci[j] = (kk < p.Ktot && r < 7) ? 0 : -1;
+      x_dh[j] = r - 3;
+      x_dw[j] = (kk & 31) >> 2;
+    } else if (kk < p.Ktot) {
+      const unsigned int t = fdiv((unsigned)kk, p.divCin);
+      const unsigned int r = fdiv(t, p.divKW);
+      x_ci[j] = kk - t * p.Cin;
+      x_dh[j] = (int)r - p.pad;
+      x_dw[j] = (int)(t - r * p.KW) - p.pad;
+    } else {
+      x_ci[j] = -1; x_dh[j] = 0; x_dw[j] = 0;
+    }
+  }
+  int y_row[YJ], y_co[YJ];
+#pragma unroll
+  for (int j = 0; j < YJ; ++j) {
+    const int row = (wave * YJ + j) * YRPI + lane / YCPR;
+    const int pc = lane % YCPR;
+    const int lc = pc ^ (tr_swz<BNC>(row) << 1);
+    const int co = c0 + lc * 8;
+    y_row[j] = row;
+    y_co[j] = (co < p.Cout) ? co : -1;
+  }
+
+  auto stage = [&](int mbase, int slot) {
+    unsigned char* sX = smem + slot * STAGE_BYTES;
+    unsigned char* sY = sX + X_BYTES;
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int m = mbase + x_row[j];
+      const bf16_t* src = zero;
+      if (p.pointwise) {
+        if (m < m_end && x_ci[j] >= 0) src = x + ((long long)m * p.Cin + x_ci[j]);
+      } else if (m < m_end && x_ci[j] >= 0) {
+        const unsigned int n = fdiv((unsigned)m, p.divHW);
+        const unsigned int rm = m - n * (p.OH * p.OW);
+        const unsigned int oh = fdiv(rm, p.divW);
+        const unsigned int ow = rm - oh * p.OW;
+        const int ih = (int)oh * p.stride + x_dh[j], iw = (int)ow * p.stride + x_dw[j];
+        // stem7: IW is the padded pitch and iw a padded column (always inside the row)
+        if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW)
+          src = x + (((n * p.IH + ih) * p.IW + iw) * p.Cin + x_ci[j]);
+      }
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sX + ((wave * XJ + j) * XRPI) * XROWB), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+      const int m = mbase + y_row[j];
+      const bf16_t* src = (m < m_end && y_co[j] >= 0) ? dy + ((long long)m * p.Cout + y_co[j]) : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sY + ((wave * YJ + j) * YRPI) * YROWB), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[KR][CR];
+#pragma unroll
+  for (int i = 0; i < KR; ++i)
+#pragma unroll
+    for (int j = 0; j < CR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.bias_slab != nullptr && tile_k == 0 && wk == 0;   // wave-uniform
+  f32x4 bacc[CR];
+#pragma unroll
+  for (int j = 0; j < CR; ++j) bacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const int r0 = 8 * g + q, r1 = r0 + 4;
+  // per-lane read offsets inside a slot (the stage is exactly one 32-deep MFMA step)
+  unsigned xoff0[KR], xoff1[KR], yoff0[CR], yoff1[CR];
+#pragma unroll
+  for (int i = 0; i < KR; ++i) {
+    const int lb = wk * KR + i;
+    xoff0[i] = r0 * XROWB + ((lb ^ tr_swz<BMK>(r0)) << 5) + 8 * pq;
+    xoff1[i] = r1 * XROWB + ((lb ^ tr_swz<BMK>(r1)) << 5) + 8 * pq;
+  }
+#pragma unroll
+  for (int j = 0; j < CR; ++j) {
+    const int lb = wc * CR + j;
+    yoff0[j] = X_BYTES + r0 * YROWB + ((lb ^ tr_swz<BNC>(r0)) << 5) + 8 * pq;
+    yoff1[j] = X_BYTES + r1 * YROWB + ((lb ^ tr_swz<BNC>(r1)) << 5) + 8 * pq;
+  }
+
+  const unsigned lds_base = (unsigned)(uintptr_t)LPTR(smem);
+  const int nsteps = (m_end - m_begin + RKR - 1) / RKR;
+  int fill_slot = 0, fill_m = m_begin, issued = 0;
+  auto issue = [&]() {
+    stage(fill_m, fill_slot);
+    fill_m += RKR;
+    fill_slot = fill_slot == NSLOT - 1 ? 0 : fill_slot + 1;
+    ++issued;
+  };
+#pragma unroll
+  for (int k = 0; k < NSLOT - 1; ++k)
+    if (k < nsteps) issue();
+  int read_slot = 0;
+  for (int t = 0; t < nsteps; ++t) {
+    ring_wait<LPW>(issued - 1 - t);              // this wave's part of stage t has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                // stage t complete for every wave; the slot of stage t-1 is free
+    if (issued < nsteps) issue();                // refill it with stage t + NSLOT - 1
+    const unsigned sl = lds_base + (unsigned)(read_slot * STAGE_BYTES);
+    read_slot = read_slot == NSLOT - 1 ? 0 : read_slot + 1;
+    // fragments of the first half, MFMAs of the first half while the second half's fragments arrive
+    bf16x8 xf[KR], yf[CR];
+#pragma unroll
+    for (int j = 0; j < CR; ++j) yf[j] = tr_read_pair_asm(sl + yoff0[j], sl + yoff1[j]);
+#pragma unroll
+    for (int i = 0; i < KH2; ++i) xf[i] = tr_read_pair_asm(sl + xoff0[i], sl + xoff1[i]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = KH2; i < KR; ++i) xf[i] = tr_read_pair_asm(sl + xoff0[i], sl + xoff1[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < KH2; ++i)
+#pragma unroll
+      for (int j = 0; j < CR; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = KH2; i < KR; ++i)
+#pragma unroll
+      for (int j = 0; j < CR; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], acc[i][j], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < CR; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[j], bacc[j], 0, 0, 0);
+    }
+  }
+
+  float* slab = p.slab + (long long)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int i = 0; i < KR; ++i)
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+      const int kk = k0 + (wk * KR + i) * 16 + 4 * (lane >> 4);
+      const int co = c0 + (wc * CR + j) * 16 + (lane & 15);
+      if (kk < p.Ktot && co < p.Cout) *(f32x4*)(slab + (long long)co * p.Ktot + kk) = acc[i][j];
+    }
+  if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+      const int co = c0 + (wc * CR + j) * 16 + (lane & 15);
+      if (co < p.Cout) p.bias_slab[(long long)split * p.Cout + co] = bacc[j][0];
+    }
+  }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]; 16 B per lane; fixed summation order.
 // A block owns OUTS consecutive float4 outputs and splits the S slabs over 256/OUTS slab lanes (4 loads in
 // flight per thread), then folds the lanes through LDS in lane order.
 template <int OUTS>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                          long long n4, int S, int accumulate) {
+                                                          long long n4, int S, int accumulate, int stem7_mask) {
   constexpr int LANES = 256 / OUTS;
   __shared__ f32x4 red[256];
   const int o = threadIdx.x % OUTS, l = threadIdx.x / OUTS;
@@ -246,8 +493,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     f32x4 s = accumulate ? ((const f32x4*)out)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < LANES; ++j) s += red[j * OUTS + o];
+    // stem filters [Cout][8 rows][8 pixels][4]: pixel 7 is padding of the layout (its "gradient" is the product with the
+    // next window's first pixel): the filter entry must stay zero, so its gradient is zero
+    if (stem7_mask && (i & 7) == 7) s = f32x4{0.f, 0.f, 0.f, 0.f};
     ((f32x4*)out)[i] = s;
   }
+}
+
+// Tile choice.  ICAMD_WGRAD_RING=0 selects the single-stage 128x128 kernel of round 1 (kept for A/B runs).
+int ring_mode() {
+  static const int d = [] { const char* e = getenv("ICAMD_WGRAD_RING"); return e ? atoi(e) : 1; }();
+  return d;
+}
+// widest tile side whose last tile is not mostly padding: 256 when the extent is a multiple of 256 or large, else 128 / 64
+int pick_side(int n) {
+  if (n <= 64) return 64;
+  if (n <= 128) return 128;
+  if (n % 256 == 0 || n >= 1024) return 256;
+  return ((n + 255) / 256 * 256 - n) * 4 <= n ? 256 : 128;     // at most 25 % padding for the 256 side
+}
+
+template <int BMK, int BNC, int WK, int WC, int NSLOT, int WPS>
+int launch_ring(const WgradParams& p, hipStream_t stream) {
+  dim3 grid((unsigned)(p.ntiles_k * p.ntiles_c * p.S));
+  hipLaunchKernelGGL((conv_wgrad_ring_kernel<BMK, BNC, WK, WC, NSLOT, WPS>), grid, dim3(64 * WK * WC), 0, stream, p);
+  return icamd_launch_status();
 }
 
 template <int BMK, int BNC>
@@ -259,54 +529,112 @@ int launch(const WgradParams& p, hipStream_t stream) {
 
 }  // namespace
 
-static inline int wgrad_tile(int n) { return n <= 64 ? 64 : 128; }
+void icamd_wgrad_tile(long long M, int Ktot, int Cout, int* bmk, int* bnc) {
+  // 256x256 ring kernel where it wins (MI355X, round-2 per-layer table in profiles/README.md): both sides multiples of 256
+  // and at least ~50 GFLOP of work (ResNet's deep 3x3 and strided 1x1 layers: 100-106 us -> 78-84 us).  Smaller problems
+  // are dominated by the fp32 slab traffic of the pixel split, which grows with the tile area, and by the 32-row stage's
+  // barrier rate: they stay on the single-stage 128 / 64 tiles.
+  const bool big = ring_mode() != 0 && Ktot % 256 == 0 && Cout % 256 == 0 && (double)M * Ktot * Cout >= 2.5e10;
+  if (big || ring_mode() == 2) { *bmk = pick_side(Ktot); *bnc = pick_side(Cout); return; }   // mode 2: every ring shape (tests)
+  *bmk = Ktot <= 64 ? 64 : 128;
+  *bnc = Cout <= 64 ? 64 : 128;
+}
+
+static bool use_ring(int bmk, int bnc) { return ring_mode() == 2 || (ring_mode() == 1 && bmk == 256 && bnc == 256); }
+
+// workgroups of this tile shape that fit one CU (LDS- or register-limited; must match the launch table below)
+static int wgs_per_cu(int bmk, int bnc) {
+  if (!use_ring(bmk, bnc)) return 3;
+  if (bmk == 256 && bnc == 256) return 1;
+  if (bmk + bnc >= 320) return 2;
+  return 3;
+}
 
 void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split) {
-  // Split of the pixel reduction: each workgroup should run ~64 stages (4096 pixels) -- long enough to amortise its
-  // prologue and its fp32 slab tile, short enough to balance -- while the grid stays within [512, 2048] workgroups
-  // (2-8 per CU).  Measured on MI355X over the ResNet-50 shapes (profiles/r01 notes).
-  static const int rows_target = []() { const char* e = getenv("ICAMD_WGRAD_ROWS"); return e ? atoi(e) : 4096; }();
-  const int bmk = wgrad_tile(Ktot), bnc = wgrad_tile(Cout);
+  // Split of the pixel reduction over S workgroups per output tile.  Cost model (MI355X, round-2 measurements): the grid
+  // runs in ceil(tiles*S / resident workgroups) rounds, a round lasts as long as one workgroup: its pixel rows plus a
+  // fixed prologue + slab-store overhead worth ~256 rows; S is chosen to minimise rounds x that, within [1, 8 rounds] and
+  // at least 16 stages per workgroup where M allows.
+  int bmk, bnc;
+  icamd_wgrad_tile(M, Ktot, Cout, &bmk, &bnc);
   const int tiles = ((Ktot + bmk - 1) / bmk) * ((Cout + bnc - 1) / bnc);
-  int s = (M + rows_target - 1) / rows_target;
-  static const int blocks_min = []() { const char* e = getenv("ICAMD_WGRAD_BLOCKS_MIN"); return e ? atoi(e) : 512; }();
-  const int smin = (blocks_min + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
-  if (s < smin) s = smin;
-  if (s > smax) s = smax;
-  const int scap = (M + BKR - 1) / BKR;
-  if (s > scap) s = scap;
-  if (s < 1) s = 1;
-  int rows = (M + s - 1) / s;
-  rows = (rows + BKR - 1) / BKR * BKR;
+  if (!use_ring(bmk, bnc)) {
+    // single-stage kernel (round 1): ~64 stages (4096 pixels) per workgroup, grid within [512, 2048] workgroups
+    int s = (M + 4095) / 4096;
+    const int smin = (512 + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
+    if (s < smin) s = smin;
+    if (s > smax) s = smax;
+    const int cap = (M + BKR - 1) / BKR;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    int r = (M + s - 1) / s;
+    r = (r + BKR - 1) / BKR * BKR;
+    *rows_per_split = r;
+    *S = (M + r - 1) / r;
+    return;
+  }
+  const int resident = 256 * wgs_per_cu(bmk, bnc);
+  static const int overhead_rows = []() { const char* e = getenv("ICAMD_WGRAD_OVERHEAD_ROWS"); return e ? atoi(e) : 256; }();
+  const int gran = RKR;
+  int scap = (M + gran - 1) / gran;
+  const int smax = (8 * resident + tiles - 1) / tiles;
+  if (scap > smax) scap = smax;
+  if (scap < 1) scap = 1;
+  long long best_cost = -1;
+  int best_s = 1;
+  for (int s = 1; s <= scap; ++s) {
+    int rows = (M + s - 1) / s;
+    rows = (rows + gran - 1) / gran * gran;
+    const int s_eff = (M + rows - 1) / rows;
+    const long long rounds = ((long long)tiles * s_eff + resident - 1) / resident;
+    const long long cost = rounds * (rows + overhead_rows);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_s = s; }
+  }
+  int rows = (M + best_s - 1) / best_s;
+  rows = (rows + gran - 1) / gran * gran;
   *rows_per_split = rows;
   *S = (M + rows - 1) / rows;
 }
 
 int icamd_wgrad_launch(WgradParams& p, hipStream_t stream) {
-  if (p.Cin % 8 != 0 || p.Cout % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
+  if ((!p.stem7 && p.Cin % 8 != 0) || p.Cout % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)p.N * p.IH * p.IW * p.Cin >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   if (p.M <= 0 || p.M >= (1 << 30)) return ICAMD_ERR_BAD_ARG;
-  const int bmk = wgrad_tile(p.Ktot), bnc = wgrad_tile(p.Cout);
+  int bmk, bnc;
+  icamd_wgrad_tile(p.M, p.Ktot, p.Cout, &bmk, &bnc);
   p.ntiles_k = (p.Ktot + bmk - 1) / bmk;
   p.ntiles_c = (p.Cout + bnc - 1) / bnc;
   p.divHW = make_fastdiv((unsigned)(p.OH * p.OW));
   p.divW = make_fastdiv((unsigned)p.OW);
   p.divCin = make_fastdiv((unsigned)p.Cin);
   p.divKW = make_fastdiv((unsigned)p.KW);
-  p.pointwise = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0) ? 1 : 0;
-  if (bmk == 64) return bnc == 64 ? launch<64, 64>(p, stream) : launch<64, 128>(p, stream);
-  return bnc == 64 ? launch<128, 64>(p, stream) : launch<128, 128>(p, stream);
+  p.pointwise = (!p.stem7 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0) ? 1 : 0;
+  if (!use_ring(bmk, bnc)) {
+    if (bmk == 64) return bnc == 64 ? launch<64, 64>(p, stream) : launch<64, 128>(p, stream);
+    return bnc == 64 ? launch<128, 64>(p, stream) : launch<128, 128>(p, stream);
+  }
+  //                                         BMK  BNC  WK WC NSLOT WPS   per wave   LDS/workgroup  workgroups/CU
+  if (bmk == 256 && bnc == 256) return launch_ring<256, 256, 2, 4, 4, 2>(p, stream);   // 128x64     128 KB         1
+  if (bmk == 256 && bnc == 128) return launch_ring<256, 128, 2, 2, 3, 2>(p, stream);   // 128x64      72 KB         2
+  if (bmk == 128 && bnc == 256) return launch_ring<128, 256, 1, 4, 3, 2>(p, stream);   // 128x64      72 KB         2
+  if (bmk == 256 && bnc == 64) return launch_ring<256, 64, 4, 1, 3, 2>(p, stream);     //  64x64      60 KB         2
+  if (bmk == 64 && bnc == 256) return launch_ring<64, 256, 1, 4, 3, 2>(p, stream);     //  64x64      60 KB         2
+  if (bmk == 128 && bnc == 128) return launch_ring<128, 128, 2, 2, 3, 3>(p, stream);   //  64x64      48 KB         3
+  if (bmk == 128 && bnc == 64) return launch_ring<128, 64, 2, 2, 3, 3>(p, stream);     //  64x32      36 KB         3
+  if (bmk == 64 && bnc == 128) return launch_ring<64, 128, 2, 2, 3, 3>(p, stream);     //  32x64      36 KB         3
+  return launch_ring<64, 64, 2, 2, 3, 3>(p, stream);                                    //  32x32      24 KB         3
 }
 
-int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream) {
+int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream,
+                             int stem7_mask) {
   if (n % 4 != 0) return ICAMD_ERR_BAD_ARG;
   const long long n4 = n / 4;
   if (n4 >= 64 * 1024) {   // large filters: 64 outputs x 4 slab lanes per block
     hipLaunchKernelGGL(slab_reduce_kernel<64>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, slab, out, n4, S,
-                       accumulate);
+                       accumulate, stem7_mask);
   } else {                 // small filters, many slabs: 16 outputs x 16 slab lanes per block
     hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, stream, slab, out, n4, S,
-                       accumulate);
+                       accumulate, stem7_mask);
   }
   return icamd_launch_status();
 }

@@ -30,6 +30,7 @@ struct IgemmParams {
   int ntaps, Ktot;       // active taps; filter row length (elements)
   int KW, pad;           // regular-tap rule of the general (Cin % 64 != 0) path: dh = tap_sign*(r - pad)
   int tap_sign, regular_taps;
+  int stem7;             // ResNet stem on the rgb4 layout (conv_igemm.hip KMODE 3)
   int ksteps, ntiles_n;  // filled by the launcher
   FastDiv divPQ, divQ, divCin, divKW;   // filled by the launcher
   short dh[ICAMD_MAX_TAPS], dw[ICAMD_MAX_TAPS], wtap[ICAMD_MAX_TAPS];
@@ -67,9 +68,12 @@ struct WgradParams {
   int S, rows_per_split;  // split of the m reduction
   int ntiles_k, ntiles_c;
   int pointwise;      // 1x1, stride 1, pad 0: the gather is the identity
+  int stem7;          // ResNet stem on the rgb4 layout: k = row*32 + pixel*4 + channel, IW = padded pitch, Cin = 4
   FastDiv divHW, divW, divCin, divKW;
 };
 int icamd_wgrad_launch(WgradParams& p, hipStream_t stream);
 void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split);
+void icamd_wgrad_tile(long long M, int Ktot, int Cout, int* bmk, int* bnc);   // output-tile sides the launcher will use
 // out[i] = (accumulate ? out[i] : 0) + sum over S slabs of slab[s][i], fixed order; n % 4 == 0
-int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream);
+int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream,
+                             int stem7_mask = 0);

@@ -270,17 +270,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ shift, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, bf16_t* __restrict__ dy,
                                                            bf16_t* __restrict__ gout, const unsigned char* __restrict__ maskbits,
-                                                           long long nvec, int cpr, int relu) {
+                                                           long long nvec, int cpr, int relu, int reverse) {
+  // `reverse`: walk the tensors from the END.  The reduce pass that ran just before streamed dout and y front to back, so
+  // their tails are what the 256 MB Infinity Cache (and L2) still hold: reading back to front meets those lines first.
   const long long stride = (long long)gridDim.x * blockDim.x;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cg = (int)(i % cpr) * 8;
+  long long k0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // the launcher makes stride and nvec multiples of cpr, so this thread's channel group never changes (either direction)
+  const int cg = (int)((reverse ? nvec - 1 - k0 : k0) % cpr) * 8;
   float mu[8], is[8], sc[8], sh[8], k1[8], k2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     mu[e] = mean[cg + e]; is[e] = invstd[cg + e]; sc[e] = scale[cg + e]; sh[e] = shift[cg + e];
     k1[e] = c1[cg + e]; k2[e] = c2[cg + e];
   }
-  for (; i < nvec; i += stride) {
+  for (; k0 < nvec; k0 += stride) {
+    const long long i = reverse ? nvec - 1 - k0 : k0;
     const u32x4 d = ((const u32x4*)dout)[i];
     const u32x4 yv = ((const u32x4*)y)[i];
     float g[8], yy[8];
@@ -403,17 +407,18 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ yB, const float* __restrict__ meanB,
                                                                 const float* __restrict__ invstdB, const float* __restrict__ scaleB,
                                                                 const float* __restrict__ cB, bf16_t* __restrict__ dyB,
-                                                                long long nvec, int cpr, int C) {
+                                                                long long nvec, int cpr, int C, int reverse) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int cg = (int)(i % cpr) * 8;
+  long long k0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = (int)((reverse ? nvec - 1 - k0 : k0) % cpr) * 8;   // see bn_bwd_apply_kernel
   float muA[8], isA[8], scA[8], k1A[8], k2A[8], muB[8], isB[8], scB[8], k1B[8], k2B[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     muA[e] = meanA[cg + e]; isA[e] = invstdA[cg + e]; scA[e] = scaleA[cg + e]; k1A[e] = cA[cg + e]; k2A[e] = cA[C + cg + e];
     muB[e] = meanB[cg + e]; isB[e] = invstdB[cg + e]; scB[e] = scaleB[cg + e]; k1B[e] = cB[cg + e]; k2B[e] = cB[C + cg + e];
   }
-  for (; i < nvec; i += stride) {
+  for (; k0 < nvec; k0 += stride) {
+    const long long i = reverse ? nvec - 1 - k0 : k0;
     const u32x4 d = ((const u32x4*)dout)[i];
     const u32x4 va = ((const u32x4*)yA)[i];
     const u32x4 vb = ((const u32x4*)yB)[i];
@@ -622,6 +627,49 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
   }
 }
 
+// ResNet stem layout: fp32 NCHW -> bf16 [B][H][Wp][4] (RGB + one zero channel), Wp = W + 8 with 3 zero columns on the left and
+// 5 on the right, so that the 7x7/2 window row of output column q is the 64 contiguous, 16 B-aligned bytes starting at padded
+// column 2q (8 pixels x 4 channels; the 8th pixel meets a zero filter tap) and no load ever crosses the image border.
+// One thread writes two adjacent padded pixels (16 B).  Same fused mixup / cutmix as pack_input_kernel.
+__global__ __launch_bounds__(256) void pack_input_rgb4_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B,
+                                                              int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                                                              int xl, int xh) {
+  const int Wp2 = (W + 8) / 2;
+  const long long total = (long long)B * H * Wp2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long hw = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long row = i / Wp2;
+    const int pp = (int)(i - row * Wp2);
+    const int b = (int)(row / H), h = (int)(row - (long long)b * H);
+    const int fb = B - 1 - b;
+    float f[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int w = 2 * pp + e - 3;
+      if (w >= 0 && w < W) {
+        const long long pix = (long long)h * W + w;
+        for (int c = 0; c < Cin; ++c) {
+          float v = x[((long long)b * Cin + c) * hw + pix];
+          if (mode == 1) {
+            const float o = x[((long long)fb * Cin + c) * hw + pix];
+            v = v * lam + o * (1.f - lam);
+          } else if (mode == 2) {
+            if (h >= yl && h < yh && w >= xl && w < xh) v = x[((long long)fb * Cin + c) * hw + pix];
+          }
+          f[4 * e + c] = v;
+        }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+    ((u32x4*)out)[i] = o;
+  }
+}
+
 inline unsigned int grid_for(long long work_items, int threads, int multiple_of) {
   static const long long cap = []() { const char* e = getenv("ICAMD_EW_BLOCKS"); return e ? atoll(e) : 1024ll; }();
   long long blocks = (work_items + threads - 1) / threads;
@@ -629,6 +677,13 @@ inline unsigned int grid_for(long long work_items, int threads, int multiple_of)
   if (blocks < 1) blocks = 1;
   if (multiple_of > 1) blocks = (blocks + multiple_of - 1) / multiple_of * multiple_of;
   return (unsigned int)blocks;
+}
+// ICAMD_BN_REVERSE=1: back-to-front traversal of the second BatchNorm-backward pass.  Measured on MI355X (ResNet-50 bs 256,
+// round 2): 5.50-5.53 ms/step of BatchNorm backward either way -- the pass is not helped by Infinity-Cache hits -- so it
+// stays off.
+inline int bn_reverse() {
+  static const int v = []() { const char* e = getenv("ICAMD_BN_REVERSE"); return e ? atoi(e) : 0; }();
+  return v;
 }
 inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
@@ -731,7 +786,7 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, act, y, mean, invstd,
-                     scale, shift, c1, c2, dy, gout, maskbits, nvec, C / 8, relu);
+                     scale, shift, c1, c2, dy, gout, maskbits, nvec, C / 8, relu, bn_reverse());
   return icamd_launch_status();
 }
 
@@ -761,7 +816,7 @@ int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, 
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_dual_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, maskbits, yA, meanA,
-                     invstdA, scaleA, cA, dyA, yB, meanB, invstdB, scaleB, cB, dyB, nvec, C / 8, C);
+                     invstdA, scaleA, cA, dyA, yB, meanB, invstdB, scaleB, cB, dyB, nvec, C / 8, C, bn_reverse());
   return icamd_launch_status();
 }
 
@@ -785,7 +840,7 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, g, (const bf16_t*)nullptr, y,
-                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, (const unsigned char*)nullptr, nvec, C / 8, 0);
+                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, (const unsigned char*)nullptr, nvec, C / 8, 0, 0);
   return icamd_launch_status();
 }
 
@@ -836,6 +891,16 @@ int icamd_pack_input_launch(const float* x, bf16_t* out, int B, int Cin, int H, 
   const long long total = (long long)B * H * W;
   hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for(total, 256, 1) * 2), dim3(256), 0, s, x, out, B, Cin, H, W, mode, lam,
                      yl, yh, xl, xh);
+  return icamd_launch_status();
+}
+
+
+int icamd_pack_input_rgb4_launch(const float* x, bf16_t* out, int B, int Cin, int H, int W, int mode, float lam, int yl,
+                                 int yh, int xl, int xh, hipStream_t s) {
+  if (Cin < 1 || Cin > 3 || W % 2 != 0) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)B * H * ((W + 8) / 2);
+  hipLaunchKernelGGL(pack_input_rgb4_kernel, dim3(grid_for(total, 256, 1) * 2), dim3(256), 0, s, x, out, B, Cin, H, W, mode,
+                     lam, yl, yh, xl, xh);
   return icamd_launch_status();
 }
 

@@ -93,6 +93,11 @@ _SIGNATURES = {
     "icamd_avgpool_fwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "icamd_avgpool_bwd": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "icamd_pack_input": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
+    "icamd_pack_input_rgb4": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, _P]),
+    "icamd_stem7x7s2_stats_rows": (c_int, [c_int, c_int, c_int]),
+    "icamd_stem7x7s2_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "icamd_stem7x7s2_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "icamd_stem7x7s2_wgrad": (c_int, [_P, _P, _P, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
     "icamd_softmax_xent": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
     "icamd_step_metrics": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "icamd_grad_norm_workspace_bytes": (c_size_t, []),

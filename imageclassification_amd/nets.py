@@ -52,11 +52,12 @@ class _Param:
 class _Conv:
     """Convolution record. weight param in arena layout [Cout_p][KH][KW][Cin_p]."""
 
-    def __init__(self, name, cin, cout, k, stride, pad, cin_p=None, cout_p=None, bias=False):
+    def __init__(self, name, cin, cout, k, stride, pad, cin_p=None, cout_p=None, bias=False, k_p=None):
         self.name = name
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.cin_p = cin_p or cin
         self.cout_p = cout_p or cout
+        self.k_p = k_p or k        # kernel extent of the arena layout (the stem stores 7x7 filters as 8x8x4, see _build_graph)
         self.has_bias = bias
         self.w = None      # _Param
         self.b = None
@@ -109,7 +110,9 @@ class ResNet(PicklableModel):
     # ------------------------------------------------------------------ structure
     def _build_graph(self, layers):
         self.convs, self.bns = [], []
-        self.stem_conv = self._conv("conv1", 3, 64, 7, 2, 3, cin_p=8)
+        # stem filters live as [64][8][8][4] (row 7, column 7, channel 3 zero): the layout icamd_stem7x7s2_fwd / _wgrad
+        # reduce over, on the [N][H][W+8][4] image icamd_pack_input_rgb4 writes
+        self.stem_conv = self._conv("conv1", 3, 64, 7, 2, 3, cin_p=4, k_p=8)
         self.stem_bn = self._bn("bn1", 64)
         self.blocks = []
         inplanes = 64
@@ -137,8 +140,8 @@ class ResNet(PicklableModel):
         self.feat_dim = inplanes
         self.fc = self._conv("fc", inplanes, self.num_classes, 1, 1, 0, cout_p=self.ncls_p, bias=True)
 
-    def _conv(self, name, cin, cout, k, stride, pad, cin_p=None, cout_p=None, bias=False):
-        c = _Conv(name, cin, cout, k, stride, pad, cin_p, cout_p, bias)
+    def _conv(self, name, cin, cout, k, stride, pad, cin_p=None, cout_p=None, bias=False, k_p=None):
+        c = _Conv(name, cin, cout, k, stride, pad, cin_p, cout_p, bias, k_p)
         self.convs.append(c)
         return c
 
@@ -175,7 +178,7 @@ class ResNet(PicklableModel):
         for m in order:
             if isinstance(m, _Conv):
                 wname = m.name + ".weight"
-                m.w = add(wname, (m.cout, m.cin, m.k, m.k), "conv", (m.cout_p, m.k, m.k, m.cin_p))
+                m.w = add(wname, (m.cout, m.cin, m.k, m.k), "conv", (m.cout_p, m.k_p, m.k_p, m.cin_p))
                 if m.has_bias:
                     m.b = add(m.name + ".bias", (m.cout,), "vec", (m.cout_p,))
             else:
@@ -260,7 +263,7 @@ class ResNet(PicklableModel):
                 t = t[:, :, None, None]
             cout, cin, kh, kw = t.shape
             full = torch.zeros(p.padded_shape)
-            full[:cout, :, :, :cin] = t.permute(0, 2, 3, 1)
+            full[:cout, :kh, :kw, :cin] = t.permute(0, 2, 3, 1)
             return full.flatten()
         full = torch.zeros(p.padded_shape)
         full[: t.numel()] = t.flatten()
@@ -269,8 +272,8 @@ class ResNet(PicklableModel):
     def _from_arena_layout(self, p, flat):
         t = flat.reshape(p.padded_shape)
         if p.kind == "conv":
-            cout, cin = p.torch_shape[0], p.torch_shape[1]
-            t = t[:cout, :, :, :cin].permute(0, 3, 1, 2).contiguous()
+            cout, cin, kh, kw = (tuple(p.torch_shape) + (1, 1))[:4]
+            t = t[:cout, :kh, :kw, :cin].permute(0, 3, 1, 2).contiguous()
             if p.name == "fc.weight":
                 t = t.reshape(cout, cin)
             return t
@@ -380,13 +383,18 @@ class ResNet(PicklableModel):
         for conv, bn in pairs:
             rm = self.buffer_arena.data_ptr() + 4 * bn.buf_offset
             hip.check(self.lib.icamd_bn_fold_filters(self._pf(conv.w), self._pf(bn.weight), self._pf(bn.bias), rm,
-                                                     rm + 4 * bn.c, BN_EPS, conv.cout_p, conv.k * conv.k * conv.cin_p,
+                                                     rm + 4 * bn.c, BN_EPS, conv.cout_p, conv.w.numel // conv.cout_p,
                                                      self.shadow_eval.data_ptr() + 2 * conv.w.offset,
                                                      self.eval_shift.data_ptr() + 4 * bn.shift_offset, s), bn.name)
         self._fold_dirty = False
 
     def _conv_act_eval(self, conv, bn, x, N, IH, IW, out, residual, relu, s):
         d = conv.desc(N, IH, IW)
+        if conv is self.stem_conv:
+            hip.check(self.lib.icamd_stem7x7s2_fwd(x, self.shadow_eval.data_ptr() + 2 * conv.w.offset, out.data_ptr(),
+                                                   self.eval_shift.data_ptr() + 4 * bn.shift_offset, None, int(relu), N, IH, IW,
+                                                   conv.cout_p, s), conv.name)
+            return d
         hip.check(self.lib.icamd_conv2d_fwd_act(ctypes.byref(d), x, self.shadow_eval.data_ptr() + 2 * conv.w.offset,
                                                 out.data_ptr(), self.eval_shift.data_ptr() + 4 * bn.shift_offset, residual,
                                                 int(relu), s), conv.name)
@@ -441,7 +449,9 @@ class ResNet(PicklableModel):
         def act(n, h, w, c):
             return torch.empty(n, h, w, c, dtype=torch.bfloat16, device=dev)
 
-        ws["x8"] = act(N, H, W, 8)
+        if W % 2:
+            raise ValueError("the ResNet stem kernels need an even input width")
+        ws["x8"] = act(N, H, W + 8, 4)      # the rgb4 stem layout (3 + 5 zero columns per row)
         d0 = self.stem_conv.desc(N, H, W)
         ws["y0"] = act(N, d0.OH, d0.OW, 64)
         ws["a0"] = act(N, d0.OH, d0.OW, 64)
@@ -450,7 +460,7 @@ class ResNet(PicklableModel):
         ws["p0_idx"] = torch.empty(N, PH, PW, 64, dtype=torch.uint8, device=dev)
         max_act = max(ws["y0"].numel(), ws["x8"].numel())
         max_stats = lib.icamd_conv2d_stats_rows(ctypes.byref(d0)) * 2 * 64
-        max_wg = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d0))
+        max_wg = lib.icamd_stem7x7s2_wgrad_workspace_bytes(N, H, W, 64)
         max_bnb = lib.icamd_bn_bwd_workspace_bytes(N * d0.OH * d0.OW, 64)
         h, w = PH, PW
         blocks_ws = []
@@ -532,16 +542,26 @@ class ResNet(PicklableModel):
         st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
         c = bn.c
         mean, invstd, scale, shift = st, st + 4 * c, st + 8 * c, st + 12 * c
+        stem = conv is self.stem_conv
+
+        def conv_fwd(stats_ptr):
+            if stem:
+                hip.check(lib.icamd_stem7x7s2_fwd(x, self._w(conv), y.data_ptr(), None, stats_ptr, 0, N, IH, IW, conv.cout_p, s),
+                          conv.name)
+            else:
+                hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x, self._w(conv), y.data_ptr(), None, None, stats_ptr, s),
+                          conv.name)
+
         if self.training:
             stats = ws["stats"].data_ptr()
-            hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x, self._w(conv), y.data_ptr(), None, None, stats, s), conv.name)
+            conv_fwd(stats)
             rows = lib.icamd_conv2d_stats_rows(ctypes.byref(d))
             rm = self.buffer_arena.data_ptr() + 4 * bn.buf_offset
             hip.check(lib.icamd_bn_train_finalize(stats, rows, c, float(N * d.OH * d.OW), self._pf(bn.weight),
                                                   self._pf(bn.bias), rm, rm + 4 * c, BN_MOMENTUM, BN_EPS, mean, invstd,
                                                   scale, shift, ws["bn_ws"].data_ptr(), s), bn.name)
         else:
-            hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x, self._w(conv), y.data_ptr(), None, None, None, s), conv.name)
+            conv_fwd(None)
             rm = self.buffer_arena.data_ptr() + 4 * bn.buf_offset
             scale = ws["scale_shift_eval"].data_ptr()
             shift = scale + 4 * 2048
@@ -563,8 +583,8 @@ class ResNet(PicklableModel):
         N, C, H, W = x_nchw.shape
         ws = self._workspace(N, H, W)
         mode, lam, box = (0, 1.0, (0, 0, 0, 0)) if mix is None else mix
-        hip.check(self.lib.icamd_pack_input(x_nchw.data_ptr(), ws["x8"].data_ptr(), N, C, H, W, mode, float(lam),
-                                            int(box[0]), int(box[1]), int(box[2]), int(box[3]), hip.stream_ptr()), "pack")
+        hip.check(self.lib.icamd_pack_input_rgb4(x_nchw.data_ptr(), ws["x8"].data_ptr(), N, C, H, W, mode, float(lam),
+                                                 int(box[0]), int(box[1]), int(box[2]), int(box[3]), hip.stream_ptr()), "pack")
         return ws
 
     def forward_packed(self, ws, logits_only=False):   # logits_only: accepted for interface parity (BatchNorm needs every conv output)
@@ -663,8 +683,12 @@ class ResNet(PicklableModel):
                 ready = torch.cuda.Event()
                 ready.record(main)
                 side.wait_event(ready)
-            hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, ws_side),
-                      conv.name + " wgrad")
+            if conv is self.stem_conv:
+                hip.check(lib.icamd_stem7x7s2_wgrad(x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, n, ih, iw, conv.cout_p, ws_side),
+                          conv.name + " wgrad")
+            else:
+                hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, ws_side),
+                          conv.name + " wgrad")
             if side is not None:
                 done = torch.cuda.Event()
                 done.record(side)
@@ -792,6 +816,10 @@ class ResNet(PicklableModel):
 
         def wgrad(conv, x_ptr, dy_ptr, n, ih, iw):
             d = conv.desc(n, ih, iw)
+            if conv is self.stem_conv:
+                hip.check(lib.icamd_stem7x7s2_wgrad(x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, n, ih, iw, conv.cout_p, s),
+                          conv.name + " wgrad")
+                return
             hip.check(lib.icamd_conv2d_wgrad(ctypes.byref(d), x_ptr, dy_ptr, self._gf(conv.w), acc, wsp, wsb, s),
                       conv.name + " wgrad")
 

@@ -226,6 +226,23 @@ int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* st
 int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                      int xl, int xh, void* stream);
 
+/* ResNet stem layout: bf16 [B][H][W+8][4] -- RGB + one zero channel, 3 zero columns left and 5 right of every row, so that
+ * the 7x7/2 window row of output column q is 64 contiguous 16 B-aligned bytes (W even).  Same mixing modes as above. */
+int icamd_pack_input_rgb4(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
+                          int xl, int xh, void* stream);
+
+/* ---- ResNet stem convolution (timm resnet conv1: 7x7, stride 2, padding 3; /root/reference/train.py:194) on that layout.
+ * w: bf16 [Cout][8][8][4] = filter[co][row][column][channel] with row 7, column 7 and channel 3 ZERO (the reduction runs
+ * over 8 x 8 x 4 = 256 entries: 1.74x the algorithmic work, against 2.67x for icamd_conv2d_fwd on 8 zero-padded channels).
+ * y / stats / bias / relu as icamd_conv2d_fwd / _fwd_act; stats rows = icamd_stem7x7s2_stats_rows.
+ * wgrad: dw fp32 [Cout][8][8][4], the padding entries come out exactly zero. */
+int icamd_stem7x7s2_stats_rows(int N, int H, int W);
+int icamd_stem7x7s2_fwd(const void* x4, const void* w, void* y, const float* bias, float* stats, int relu, int N, int H,
+                        int W, int Cout, void* stream);
+size_t icamd_stem7x7s2_wgrad_workspace_bytes(int N, int H, int W, int Cout);
+int icamd_stem7x7s2_wgrad(const void* x4, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
+                          int N, int H, int W, int Cout, void* stream);
+
 /* ---- loss + metrics (criterion engine.py:49,52,178,181; accuracy / TP-FP-FN engine.py:82-97,184-196) ---- */
 /* logits bf16 [B][ld]; targets int64; target distribution lam*onehot_s(y1) + (1-lam)*onehot_s(y2).
  * loss_rows float[B]; pred int32[B] (optional argmax); dlogits bf16 [B][ld] (optional) = (softmax - t)*gscale */

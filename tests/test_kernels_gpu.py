@@ -288,7 +288,23 @@ def test_pointwise_gelu_epilogues(lib, case):
     assert torch.equal(dz1, dz2)
 
 
-WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0)]
+WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0),
+                            (4, 14, 14, 256, 256, 3, 1, 1),      # 256x256 ring tile: 9 filter tiles, ragged last stage
+                            (3, 9, 9, 512, 256, 1, 1, 0), (2, 14, 14, 256, 512, 3, 2, 1)]
+
+
+def test_conv_wgrad_every_ring_tile_shape():
+    """The ring-pipelined weight-gradient kernel is selected by problem size (256x256 tiles for >= 50 GFLOP layers, covered
+    at full size by tests/test_fullsize_gpu.py); ICAMD_WGRAD_RING=2 routes EVERY problem to it, so the same parity cases run
+    once more through all nine of its tile shapes (child process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ICAMD_WGRAD_RING="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_conv_wgrad and not every_ring"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES)
@@ -609,6 +625,89 @@ def test_pack_input_mixup_cutmix(lib, mode):
     got = out.float().cpu()
     assert R.max_bf16_ulp(got, ref) <= 1.0 and R.rel_l2(got, ref) <= 1e-3
     assert torch.equal(got[..., 3:], torch.zeros(B, H, W, 5))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_pack_input_rgb4_stem_layout(lib, mode):
+    """[B][H][W+8][4]: RGB + zero channel, 3 zero columns left / 5 right; same fused mixup / cutmix as icamd_pack_input."""
+    hip = _hip()
+    B, H, W = 4, 10, 12
+    x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(40))
+    out = torch.full((B, H, W + 8, 4), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lam, box = 0.37, (2, 7, 3, 9)
+    xdev = x.to(DEV)
+    assert lib.icamd_pack_input_rgb4(hip.ptr(xdev), hip.ptr(out), B, 3, H, W, mode, lam, *box, hip.stream_ptr()) == 0
+    sync()
+    ref = R.pack_input(x, mode, lam, box)[..., :3]
+    got = out.float().cpu()
+    assert torch.equal(got[:, :, 3:3 + W, :3], ref)
+    assert torch.equal(got[..., 3], torch.zeros(B, H, W + 8))
+    assert torch.equal(got[:, :, :3], torch.zeros(B, H, 3, 4)) and torch.equal(got[:, :, 3 + W:], torch.zeros(B, H, 5, 4))
+    assert lib.icamd_pack_input_rgb4(hip.ptr(xdev), hip.ptr(out), B, 3, H, 13, 0, 1.0, 0, 0, 0, 0, hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64), (3, 30, 34, 64), (1, 64, 64, 72), (2, 9, 8, 64)])
+def test_stem7x7s2_fwd_and_wgrad(lib, case):
+    """ResNet stem (7x7 stride 2 pad 3, timm resnet conv1) on the rgb4 layout against torch's convolution of the same bf16
+    values: output and BatchNorm statistics partials, fused bias + ReLU (eval form), and the weight gradient, whose padding
+    entries (row 7, column 7, channel 3 of the [Cout][8][8][4] arena layout) must be exactly zero."""
+    hip = _hip()
+    N, H, W, Cout = case
+    g = torch.Generator().manual_seed(77)
+    x = R.bf16_round(torch.randn(N, 3, H, W, generator=g))
+    w = R.bf16_round(torch.randn(Cout, 7, 7, 3, generator=g) * 0.08)           # [Cout][KH][KW][Cin]
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x4 = torch.empty(N, H, W + 8, 4, dtype=torch.bfloat16, device=DEV)
+    xdev = x.to(DEV)
+    assert lib.icamd_pack_input_rgb4(hip.ptr(xdev), hip.ptr(x4), N, 3, H, W, 0, 1.0, 0, 0, 0, 0, hip.stream_ptr()) == 0
+    wp = torch.zeros(Cout, 8, 8, 4)
+    wp[:, :7, :7, :3] = w
+    wd = to_dev_bf16(wp)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    ref = R.conv2d_fwd(x_nhwc, w, 2, 3)
+    assert tuple(ref.shape) == (N, OH, OW, Cout)
+    y = torch.full((N, OH, OW, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rows = lib.icamd_stem7x7s2_stats_rows(N, H, W)
+    assert rows == (N * OH * OW + 127) // 128
+    stats = torch.full((rows, 2, Cout), float("nan"), device=DEV)
+    assert lib.icamd_stem7x7s2_fwd(hip.ptr(x4), hip.ptr(wd), hip.ptr(y), None, hip.ptr(stats), 0, N, H, W, Cout,
+                                   hip.stream_ptr()) == 0
+    sync()
+    got = y.float().cpu()
+    assert torch.isfinite(got).all() and R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
+    s1, s2 = R.conv2d_stats(got)
+    st = stats.double().cpu().sum(0)
+    assert torch.allclose(st[0], s1, rtol=1e-4, atol=1e-2) and torch.allclose(st[1], s2, rtol=1e-4, atol=1e-2)
+    # eval form: bias + ReLU fused, no statistics
+    bias = torch.randn(Cout, generator=g)
+    bd = bias.to(DEV)
+    assert lib.icamd_stem7x7s2_fwd(hip.ptr(x4), hip.ptr(wd), hip.ptr(y), hip.ptr(bd), None, 1, N, H, W, Cout,
+                                   hip.stream_ptr()) == 0
+    sync()
+    ref_act = R.bf16_round(torch.relu(R.nchw_to_nhwc(torch.nn.functional.conv2d(x, w.permute(0, 3, 1, 2), None, 2, 3)) + bias))
+    assert R.rel_l2(y.float().cpu(), ref_act) <= 1e-3
+    # weight gradient
+    dy = rnd_bf16(N, OH, OW, Cout, seed=78)
+    dyd = to_dev_bf16(dy)
+    wsb = lib.icamd_stem7x7s2_wgrad_workspace_bytes(N, H, W, Cout)
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    dw = torch.full((Cout, 8, 8, 4), 5.0, device=DEV)
+    assert lib.icamd_stem7x7s2_wgrad(hip.ptr(x4), hip.ptr(dyd), hip.ptr(dw), 0, hip.ptr(ws), wsb, N, H, W, Cout,
+                                     hip.stream_ptr()) == 0
+    sync()
+    rw = R.conv2d_wgrad(x_nhwc, dy, (7, 7), 2, 3)                            # [Cout][7][7][3]
+    gw = dw.cpu()
+    assert R.rel_l2(gw[:, :7, :7, :3], rw) <= 1e-4
+    pad = gw.clone()
+    pad[:, :7, :7, :3] = 0
+    assert float(pad.abs().max()) == 0.0
+    assert lib.icamd_stem7x7s2_wgrad(hip.ptr(x4), hip.ptr(dyd), hip.ptr(dw), 1, hip.ptr(ws), wsb, N, H, W, Cout,
+                                     hip.stream_ptr()) == 0
+    sync()
+    assert R.rel_l2(dw.cpu()[:, :7, :7, :3], 2 * rw) <= 1e-4
+    assert lib.icamd_stem7x7s2_wgrad(hip.ptr(x4), hip.ptr(dyd), hip.ptr(dw), 0, hip.ptr(ws), wsb - 1, N, H, W, Cout,
+                                     hip.stream_ptr()) == 3
 
 
 @pytest.mark.parametrize("cfg", [(8, 1000, 1024, 0.0, 1.0), (8, 1000, 1024, 0.1, 1.0), (6, 1000, 1024, 0.1, 0.3),

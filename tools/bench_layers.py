@@ -49,6 +49,19 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) * 1e3 / reps
 
+        if cin == 8:   # the ResNet stem runs on its own layout / entry points ([N][H][W+8][4] image, [Cout][8][8][4] filters)
+            x4 = torch.randn(N, h, h + 8, 4, device="cuda").to(torch.bfloat16)
+            w4 = (torch.randn(cout, 8, 8, 4, device="cuda") * 0.05).to(torch.bfloat16)
+            wsb4 = lib.icamd_stem7x7s2_wgrad_workspace_bytes(N, h, h, cout)
+            ws4 = torch.empty(wsb4, dtype=torch.uint8, device="cuda")
+            dw4 = torch.empty(cout, 8, 8, 4, device="cuda")
+            t_f = timeit(lambda: hip.check(lib.icamd_stem7x7s2_fwd(x4.data_ptr(), w4.data_ptr(), y.data_ptr(), None, stats.data_ptr(), 0, N, h, h, cout, s)))
+            t_w = timeit(lambda: hip.check(lib.icamd_stem7x7s2_wgrad(x4.data_ptr(), dy.data_ptr(), dw4.data_ptr(), 0, ws4.data_ptr(), wsb4, N, h, h, cout, s)))
+            gf_ = gf
+            print(f"{'stem 7x7 s2 224 (rgb4 layout)':34s} {M:8d} {gf:7.1f} | {t_f:8.1f} {gf/t_f*1e3:6.0f} {0:6.0f} | {float('nan'):8.1f} {0:6.0f} fused {float('nan'):8.1f} | {t_w:8.1f} {gf/t_w*1e3:6.0f}")
+            tot["fwd"] += t_f * cnt; totf["fwd"] += gf * cnt
+            tot["wgrad"] += t_w * cnt; totf["wgrad"] += gf * cnt
+            continue
         t_f = timeit(lambda: hip.check(lib.icamd_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, stats.data_ptr(), s)))
         t_d = float("nan")
         if cin != 8:
