@@ -168,6 +168,14 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
                          int gelu_inplace = 0) {
   if (!conv_desc_ok(d) || x == nullptr || w == nullptr || y == nullptr) return ICAMD_ERR_BAD_ARG;
   if ((long long)d->N * d->OH * d->OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
+  if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && addend == nullptr && gelu_out == nullptr &&
+      !gelu_inplace && icamd_halo3x3_wanted(d->N, d->IH, d->IW, d->Cin, d->Cout)) {
+    Halo3x3Params h;
+    memset(&h, 0, sizeof(h));
+    h.in = (const bf16_t*)x; h.wt = (const bf16_t*)w; h.out = (bf16_t*)y; h.bias = bias; h.stats = stats; h.relu = relu;
+    h.N = d->N; h.H = d->IH; h.W = d->IW; h.C = d->Cin; h.Cout = d->Cout;
+    return icamd_halo3x3_launch(h, (hipStream_t)stream);
+  }
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && stats == nullptr &&
       icamd_gemm_nt_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
     GemmNtParams g;
@@ -239,6 +247,15 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
     g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.addend = (const bf16_t*)addend;
     g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout; g.gelu_z = (const bf16_t*)gelu_z;
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
+  }
+  if (d->KH == 3 && d->KW == 3 && st == 1 && d->pad == 1 && addend == nullptr && addend_bits == nullptr && f == nullptr &&
+      gelu_z == nullptr && icamd_halo3x3_wanted(d->N, d->IH, d->IW, d->Cout, d->Cin)) {
+    // dX = conv(dY, transposed filter, mirrored taps): same spatial size in and out for stride 1 / pad 1
+    Halo3x3Params h;
+    memset(&h, 0, sizeof(h));
+    h.in = (const bf16_t*)dy; h.wt = (const bf16_t*)w_t; h.out = (bf16_t*)dx; h.flip = 1;
+    h.N = d->N; h.H = d->IH; h.W = d->IW; h.C = d->Cout; h.Cout = d->Cin;
+    return icamd_halo3x3_launch(h, (hipStream_t)stream);
   }
   float* partials = f ? f->partials : nullptr;
   // one launch per output parity class (ph, pw): pixels h = st*p + ph, w = st*q + pw receive only the taps

@@ -1,0 +1,373 @@
+// 3x3 / stride 1 / padding 1 convolution for gfx950 with the input tile staged ONCE per 64-channel slice ("halo" form):
+// forward and data gradient of the ResNet 3x3 layers (reference: timm Bottleneck.conv2 / BasicBlock.conv1,2 under
+// model(samples) and loss.backward(), /root/reference/engine.py:48,51,64,72).
+//
+// Why: rocprofv3 counters on MI355X (profiles/README.md, round 2) show the implicit-GEMM kernel of conv_igemm.hip is bound
+// by L2 request bandwidth on these layers (TCC busy 79-87 %, MFMA busy 25-32 %): with a 128-pixel tile it re-gathers every
+// input pixel once per tap (9x) and re-reads the whole filter once per tile, ~0.9-1.4 GB of L2 -> LDS traffic for layers
+// whose operands are 50-230 MB.  Here
+//   * an output tile is BM (256 or 128) CONSECUTIVE pixels in (n, h, w) raster order; all nine taps of those pixels lie
+//     in the raster range [m0 - W - 1, m0 + BM + W] of the input, which is staged once per 64-channel slice as
+//     [slot][64 ch] rows of 128 B (LDS-DMA; the 16 B chunks of a row are ROTATED by slot & 7, which keeps ds_read_b128
+//     conflict-free for a 16-slot fragment at ANY alignment and is additive in the tap offset): 1.06-1.45x instead of 9x;
+//   * a tap is then only an offset dh*W + dw on the slot index of the A-fragment reads; taps that leave the image (the
+//     raster neighbour is a pixel of another row / image) are zeroed per lane from a 9-bit validity mask;
+//   * the filter streams through a ring of NB LDS slots, one (tap, 32-channel half slice) stage of [BN][32] per slot,
+//     filled NB-1 stages ahead with counted s_waitcnt vmcnt and one raw s_barrier per stage (the gemm_nt.hip scheme);
+//   * four waves as WM (pixels) x WN (channels); a wave owns up to 128 x 64 accumulators, so a stage is up to 32 MFMAs
+//     (v_mfma_f32_16x16x32_bf16) per wave for 12 ds_read_b128.
+// L2 -> LDS bytes per flop drop 3-4x and the layer becomes MFMA-bound.
+// The data gradient of a stride-1 3x3 convolution is the same computation on dY with the transposed filter
+// [Cin][3][3][Cout] and mirrored taps (flip = 1).
+// Epilogue as conv_igemm.hip: lanes own 4 consecutive channels of a pixel, bias added in fp32, one rounding, bf16 tile
+// through LDS, 16 B coalesced row stores, optional ReLU, optional per-channel sum / sum-of-squares of the rounded outputs
+// as one partial row per 128 pixels (BatchNorm statistics, no float atomics).
+#include "common.h"
+#include "icamd_internal.h"
+#include <cstdlib>
+
+namespace {
+
+template <int N> __device__ __forceinline__ void halo_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// 16 B chunk swizzle of the filter stage's 64 B rows (gemm_nt.hip): chunk' = chunk ^ swzq((row >> 2) & 3)
+__device__ __forceinline__ int swzq(int blk) { return (0x78 >> (2 * blk)) & 3; }
+
+// WN: waves along the channel dimension (1 or 2; 4 / WN along pixels); MFR: 16-pixel fragments per wave along M;
+// LA: A-staging LDS-DMA instructions per wave and slice (8 slots each): 4 * LA * 8 > BM + 2 * W + 2; NB: filter ring depth.
+// KS: channels per filter stage (64: [BN][64] stages of 128 B rows; 32: [BN][32] stages of 64 B rows, twice as many barriers
+// but a ring twice as deep in the same LDS).  Measured on MI355X: KS = 64 is faster for BN = 128, KS = 32 for BN = 64.
+template <int BN, int WN, int MFR, int LA, int NB, int KS, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_halo_kernel(const Halo3x3Params p) {
+  constexpr int WM = 4 / WN;
+  constexpr int BM = WM * MFR * 16;
+  constexpr int NJ = BN / WN / 16;             // 16-channel fragments per wave along N
+  constexpr int A_SLOTS = 4 * LA * 8;
+  constexpr int ZERO_SLOT = A_SLOTS - 1;       // the last slot is staged from the zero page: every tap that leaves the image
+  constexpr int A_BYTES = A_SLOTS * 128;       // reads it (the launcher sizes LA so that the tile needs < A_SLOTS slots)
+  constexpr int B_STAGE = BN * KS * 2;         // one tap of KS channels: [BN][KS] bf16
+  constexpr int LB = BN * KS / 2048;           // filter LDS-DMA instructions per wave and stage (1 KiB each, 4 waves)
+  static_assert(KS == 32 || KS == 64, "filter stage width");
+  constexpr int RING = NB * B_STAGE;
+  constexpr int EPI_BYTES = BM * BN * 2;
+  constexpr int LDS_BYTES = (A_BYTES + RING > EPI_BYTES) ? A_BYTES + RING : EPI_BYTES;
+  static_assert(NB >= 2 && NB <= 8 && (WN == 1 || WN == 2) && LB >= 1, "configuration");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  unsigned char* const sA = smem;
+  unsigned char* const sB = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // XCD-aware tile order (blocks b and b+8 share an XCD): the channel tiles of one pixel tile stay on one XCD
+  const unsigned int nblk = gridDim.x;
+  unsigned int L;
+  {
+    const unsigned int xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned int q = nblk >> 3, r = nblk & 7u;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = L / p.ntiles_n, tile_n = L - tile_m * p.ntiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int W = p.W, C = p.C;
+  const bf16_t* __restrict__ in = p.in;
+  const bf16_t* __restrict__ wt = p.wt;
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+
+  // ---- A staging roles: instruction j of this wave covers slots (wave*LA + j)*8 .. +7; lane -> (slot, swizzled chunk).
+  // The source offset is recomputed per slice (twelve multiply-adds once per nine stages) instead of living in registers.
+  const int a_slot_lane = lane >> 3;
+  // ---- B staging roles: an instruction covers 1 KiB of the stage = 8 rows of 128 B (KS 64) or 16 rows of 64 B (KS 32)
+  int b_src[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    int row, lc;
+    if constexpr (KS == 64) {
+      row = (wave * LB + j) * 8 + (lane >> 3);
+      lc = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    } else {
+      row = (wave * LB + j) * 16 + (lane >> 2);
+      lc = ((lane & 3) ^ swzq((row >> 2) & 3)) * 8;
+    }
+    const int co = n0 + row;
+    b_src[j] = (co < p.Cout) ? co * 9 * C + lc : -1;
+  }
+  auto stage_a = [&](int slice) {
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const int slot = (wave * LA + j) * 8 + a_slot_lane;
+      const int pix = m0 - (W + 1) + slot;
+      const int lc = (((lane & 7) - slot) & 7) * 8;      // position pos holds logical chunk (pos - slot) & 7
+      const bf16_t* src = (pix >= 0 && pix < p.M && slot != ZERO_SLOT) ? in + ((long long)pix * C + slice * 64 + lc) : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sA + (wave * LA + j) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_b = [&](int slice, int tap, int kk, int slot) {
+    const int wtap = p.flip ? 8 - tap : tap;
+    const int off = wtap * C + slice * 64 + kk * 32;   // kk = 0 for 64-channel stages
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const bf16_t* src = b_src[j] >= 0 ? wt + (b_src[j] + off) : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sB + slot * B_STAGE + (wave * LB + j) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane pixel state of the MFR fragments this lane reads: slot of the CENTRE tap and the 9-bit tap validity
+  int slot0[MFR];
+  unsigned int vmask[MFR];
+#pragma unroll
+  for (int i = 0; i < MFR; ++i) {
+    const int ml = wm * (BM / WM) + i * 16 + fr;
+    const int m = m0 + ml;
+    slot0[i] = ml + W + 1;
+    unsigned int mk = 0;
+    if (m < p.M) {
+      const unsigned int n = fdiv((unsigned)m, p.divHW);
+      const unsigned int rem = m - n * (p.H * W);
+      const int h = (int)fdiv(rem, p.divW);
+      const int w = (int)(rem - (unsigned)h * W);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dh = t / 3 - 1, dw = t % 3 - 1;
+        if ((unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)W) mk |= 1u << t;
+      }
+    }
+    vmask[i] = mk;
+  }
+  f32x4 acc[NJ][MFR];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nslices = C >> 6;
+  constexpr int SPT = 64 / KS;                 // filter stages per tap
+  const int nstages = nslices * 9 * SPT;
+  // prologue: slice 0 of the input, then the first NB-1 filter stages
+  stage_a(0);
+  int issue_q = 0, issue_slice = 0, issue_tap = 0, issue_kk = 0, fill = 0;
+  auto issue_b = [&]() {
+    stage_b(issue_slice, issue_tap, issue_kk, fill);
+    fill = fill == NB - 1 ? 0 : fill + 1;
+    ++issue_q;
+    if (++issue_kk == SPT) {
+      issue_kk = 0;
+      if (++issue_tap == 9) { issue_tap = 0; ++issue_slice; }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < NB - 1; ++k)
+    if (issue_q < nstages) issue_b();
+
+  // filter fragment: row (channel) wn*(BN/WN) + j*16 + fr, 16 B chunk fq (+4 for the second half of a 64-wide stage)
+  const int b_row = wn * (BN / WN) + fr;
+  const int b_frag = KS == 64 ? b_row * 128 : b_row * 64 + ((fq ^ swzq((fr >> 2) & 3)) << 4);
+  const int bsw = (fr >> 1) & 7;
+  int read = 0, q = 0;
+  for (int slice = 0; slice < nslices; ++slice) {
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int trow = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+      const int doff = (trow - 1) * W + (tap - 3 * trow - 1);
+      const unsigned int tbit = 1u << tap;
+      // A-fragment byte addresses of this tap: invalid lanes read the zero row (one select on the slot instead of four on
+      // the data); the second 32-channel half of the slice is the same address with chunk bit 2 flipped
+      int aaddr[MFR];
+#pragma unroll
+      for (int i = 0; i < MFR; ++i) {
+        const int sl = (vmask[i] & tbit) ? slot0[i] + doff : ZERO_SLOT;
+        aaddr[i] = sl * 128 + (((fq + sl) & 7) << 4);
+      }
+#pragma unroll
+      for (int st = 0; st < SPT; ++st, ++q) {
+        // Wait for this wave's part of filter stage q (and, at the first stage of a slice, of the input tile, issued before
+        // it).  In flight behind it: the younger filter stages -- the ring keeps NB-1 ahead, fewer at the very end.
+        {
+          const int younger = issue_q - 1 - q;
+          if (younger >= 4) halo_wait_vmcnt<4 * LB>();
+          else if (younger == 3) halo_wait_vmcnt<3 * LB>();
+          else if (younger == 2) halo_wait_vmcnt<2 * LB>();
+          else if (younger == 1) halo_wait_vmcnt<LB>();
+          else halo_wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // stage q landed for every wave; the ring slot of stage q-1 is free
+        if (issue_q < nstages) issue_b();
+        const unsigned char* sb = sB + read * B_STAGE + b_frag;
+        read = read == NB - 1 ? 0 : read + 1;
+#pragma unroll
+        for (int kk = (KS == 64 ? 0 : st); kk < (KS == 64 ? 2 : st + 1); ++kk) {
+          bf16x8 wf[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if constexpr (KS == 64) wf[j] = *(const bf16x8*)(sb + j * 2048 + (((kk * 4 + fq) ^ bsw) << 4));
+            else wf[j] = *(const bf16x8*)(sb + j * 1024);
+          }
+#pragma unroll
+          for (int i = 0; i < MFR; ++i) {
+            const bf16x8 xf = *(const bf16x8*)(sA + (kk ? (aaddr[i] ^ 64) : aaddr[i]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[j][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (slice + 1 < nslices) {
+      // every wave is done with this slice's input tile once it has passed the next barrier; the tile is re-staged after a
+      // dedicated one (single buffer: the other workgroup on the CU covers the reload latency)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      stage_a(slice + 1);
+      // these LA instructions are YOUNGER than the filter stages already in flight, so the counted waits above (which only
+      // allow for filter stages) would let the next stage start too early: drain here, the filter ring refills behind it
+      halo_wait_vmcnt<0>();
+    }
+  }
+  __syncthreads();   // all fragment reads done: LDS becomes the output tile
+
+  // ---- epilogue: MFMA layout (lane: pixel = fr, 4 consecutive channels) -> bias -> [relu] -> bf16 -> LDS [BM][BN] ----
+  constexpr int ROWB = BN * 2, CPR = BN / 8;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cl = wn * (BN / WN) + j * 16 + 4 * fq;
+    const int cg = n0 + cl;
+    const int cgc = cg < p.Cout ? cg : 0;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
+#pragma unroll
+    for (int i = 0; i < MFR; ++i) {
+      const int ml = wm * (BM / WM) + i * 16 + fr;
+      f32x4 v = acc[j][i] + b4;
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+      }
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      const int slot = cl >> 2;
+      *(u32x2*)(smem + ml * ROWB + ((((slot >> 1) ^ ml) & (CPR - 1)) << 4) + ((slot & 1) << 3)) = pk;
+    }
+  }
+  __syncthreads();
+  constexpr int RPP = 256 / CPR;           // rows per pass of the whole workgroup
+  constexpr int NPASS = BM / RPP;
+  const int cp = tid & (CPR - 1), rg = tid / CPR;
+  const int co = n0 + cp * 8;
+  const bool co_ok = co < p.Cout;
+  float s1[2][8], s2[2][8];                // statistics of the two 128-pixel halves of a 256-pixel tile
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[hh][e] = 0.f; s2[hh][e] = 0.f; }
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int ml = ps * RPP + rg;
+    const int m = m0 + ml;
+    const u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ ml) & (CPR - 1)) << 4));
+    if (m < p.M && co_ok) {
+      *(u32x4*)(p.out + (long long)m * p.Cout + co) = o;
+      if (p.stats != nullptr) {
+        const int hh = (BM == 256) ? (ps * RPP >= 128 ? 1 : 0) : 0;   // RPP divides 128: a pass never straddles the halves
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bf16_lo(o[e]), hi = bf16_hi(o[e]);
+          s1[hh][2 * e] += lo; s2[hh][2 * e] += lo * lo;
+          s1[hh][2 * e + 1] += hi; s2[hh][2 * e + 1] += hi * hi;
+        }
+      }
+    }
+  }
+  if (p.stats != nullptr) {
+    __syncthreads();
+    float* red = (float*)smem;             // [RPP][2][BN] per half, halves one after the other
+    constexpr int HALVES = BM / 128;
+#pragma unroll
+    for (int hh = 0; hh < HALVES; ++hh) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[((hh * RPP + rg) * 2 + 0) * BN + cp * 8 + e] = s1[hh][e];
+        red[((hh * RPP + rg) * 2 + 1) * BN + cp * 8 + e] = s2[hh][e];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < HALVES * 2 * BN; idx += 256) {
+      const int hh = idx / (2 * BN), rest = idx - hh * 2 * BN;
+      const int which = rest / BN, c = rest - which * BN;
+      float s = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RPP; ++g) s += red[((hh * RPP + g) * 2 + which) * BN + c];
+      const long long row = (long long)tile_m * HALVES + hh;
+      if (n0 + c < p.Cout && row * 128 < p.M) p.stats[(row * 2 + which) * p.Cout + n0 + c] = s;
+    }
+  }
+}
+
+template <int BN, int WN, int MFR, int LA, int NB, int KS, int WPS>
+int launch_halo(const Halo3x3Params& p, hipStream_t stream) {
+  constexpr int BM = (4 / WN) * MFR * 16;
+  const int ntm = (p.M + BM - 1) / BM;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WN, MFR, LA, NB, KS, WPS>), dim3((unsigned)(ntm * p.ntiles_n)), dim3(256), 0,
+                     stream, p);
+  return icamd_launch_status();
+}
+
+int halo_mode() {
+  static const int m = [] { const char* e = getenv("ICAMD_CONV3X3_HALO"); return e ? atoi(e) : 1; }();
+  return m;
+}
+
+}  // namespace
+
+bool icamd_halo3x3_wanted(int N, int H, int W, int C, int Cout) {
+  if (halo_mode() == 0) return false;
+  // Default: the layers where it is faster than the implicit-GEMM kernel on MI355X at batch 256 (profiles/README.md,
+  // round 2): >= 256 channels (256->256 at 14x14: 72 -> 63 us; 512->512 at 7x7: 85 -> 70 us).  At 64 / 128 channels the two
+  // tie (the input tile is re-staged per 64-channel slice with nothing to overlap), so those stay on conv_igemm.hip.
+  // ICAMD_CONV3X3_HALO=2 / 3 force the 128- / 256-pixel tiles for every eligible layer (tests).
+  if (halo_mode() == 1 && C < 256) return false;
+  if (C % 64 != 0 || Cout % 8 != 0 || W < 3 || H < 3) return false;
+  if ((long long)N * H * W >= (1ll << 30)) return false;
+  if (2 * W + 3 + 128 > 4 * 12 * 8) return false;       // widest staged tile: 384 slots
+  return true;
+}
+
+int icamd_halo3x3_launch(Halo3x3Params& p, hipStream_t stream) {
+  if (!icamd_halo3x3_wanted(p.N, p.H, p.W, p.C, p.Cout)) return ICAMD_ERR_UNSUPPORTED;
+  p.M = p.N * p.H * p.W;
+  p.divHW = make_fastdiv((unsigned)(p.H * p.W));
+  p.divW = make_fastdiv((unsigned)p.W);
+  const int bn = p.Cout <= 64 ? 64 : 128;
+  p.ntiles_n = (p.Cout + bn - 1) / bn;
+  // 256-pixel tiles when they still give every CU ~1.5 workgroups, else 128-pixel tiles (7x7 maps at batch 256)
+  const long long tiles256 = (long long)((p.M + 255) / 256) * p.ntiles_n;
+  const bool big = halo_mode() == 2 ? false : (halo_mode() == 3 ? true : tiles256 >= 384);
+  const int slots = (big ? 256 : 128) + 2 * p.W + 2 + 1;   // + the zero row
+  const int la = (slots + 31) / 32;                       // instructions per wave (8 slots each, 4 waves)
+  if (la > 12) return ICAMD_ERR_UNSUPPORTED;
+  // LDS per workgroup = 4 KB * LA (input tile) + filter ring <= 80 KB: two workgroups per CU
+  if (bn == 128) {   // 2 x 2 waves, 128 x 64 (or 64 x 64) accumulators per wave; 16 KB filter stages of 64 channels
+    if (big) {
+      if (la <= 9) return launch_halo<128, 2, 8, 9, 2, 64, 2>(p, stream);      // 36 + 32 = 68 KB
+      if (la <= 10) return launch_halo<128, 2, 8, 10, 2, 64, 2>(p, stream);    // 40 + 32 = 72 KB
+      return launch_halo<128, 2, 8, 12, 2, 64, 2>(p, stream);                  // 48 + 32 = 80 KB
+    }
+    if (la <= 5) return launch_halo<128, 2, 4, 5, 3, 64, 2>(p, stream);        // 20 + 48 = 68 KB
+    if (la <= 6) return launch_halo<128, 2, 4, 6, 3, 64, 2>(p, stream);
+    return launch_halo<128, 2, 4, 8, 3, 64, 2>(p, stream);                     // 32 + 48 = 80 KB
+  }
+  // Cout <= 64: 4 x 1 waves, every wave reads all four filter fragments (64 x 64 accumulators per wave); 4 KB stages of 32
+  if (big) {
+    if (la <= 9) return launch_halo<64, 1, 4, 9, 6, 32, 2>(p, stream);         // 36 + 24 = 60 KB
+    if (la <= 10) return launch_halo<64, 1, 4, 10, 6, 32, 2>(p, stream);
+    return launch_halo<64, 1, 4, 12, 6, 32, 2>(p, stream);                     // 48 + 24 = 72 KB
+  }
+  if (la <= 5) return launch_halo<64, 1, 2, 5, 6, 32, 3>(p, stream);
+  if (la <= 6) return launch_halo<64, 1, 2, 6, 6, 32, 3>(p, stream);
+  return launch_halo<64, 1, 2, 8, 6, 32, 3>(p, stream);
+}

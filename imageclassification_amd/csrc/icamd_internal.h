@@ -38,6 +38,22 @@ struct IgemmParams {
 int icamd_igemm_launch(IgemmParams& p, hipStream_t stream);
 int icamd_igemm_pick_bn(int Cout);
 
+// 3x3 / stride 1 / pad 1 convolution, input tile staged once per 64-channel slice (conv3x3_halo.hip)
+struct Halo3x3Params {
+  const bf16_t* in;      // [N][H][W][C]
+  const bf16_t* wt;      // [Cout][3][3][C]
+  bf16_t* out;           // [N][H][W][Cout]
+  const float* bias;     // optional [Cout]
+  float* stats;          // optional [ceil(M/128)][2][Cout]
+  int relu;
+  int flip;              // 1: mirrored taps (data gradient with the transposed filter)
+  int N, H, W, C, Cout;
+  int M, ntiles_n;       // filled by the launcher
+  FastDiv divHW, divW;
+};
+bool icamd_halo3x3_wanted(int N, int H, int W, int C, int Cout);
+int icamd_halo3x3_launch(Halo3x3Params& p, hipStream_t stream);
+
 // Dense NT GEMM for big pointwise problems: out[m][n] = sum_k A[m][k] * B[n][k] (+ bias[n]) (+ addend[m][n])
 struct GemmNtParams {
   const bf16_t* A;       // [M][K]

@@ -288,6 +288,74 @@ def test_pointwise_gelu_epilogues(lib, case):
     assert torch.equal(dz1, dz2)
 
 
+HALO_CASES = [  # N, H, W, C, Cout: 3x3 stride 1 pad 1 layers routed to csrc/conv3x3_halo.hip
+    (4, 14, 14, 256, 256), (2, 28, 28, 128, 128), (2, 56, 56, 64, 64), (6, 7, 7, 512, 512), (3, 9, 7, 64, 72),
+    (2, 13, 11, 128, 256), (1, 3, 3, 64, 64), (5, 16, 16, 64, 128),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_fwd_and_dgrad(lib, case):
+    """The halo-staged 3x3 kernel (forward with BatchNorm statistics, inference form with bias + ReLU, and the data gradient
+    = mirrored taps on the transposed filter) against torch's convolution: image borders, tiles that straddle images and
+    rows, ragged last tiles, channel counts that are not a multiple of the tile."""
+    hip = _hip()
+    N, H, W, C, Cout = case
+    d = hip.conv_desc(N, H, W, C, Cout, 3, 3, 1, 1)
+    x = rnd_bf16(N, H, W, C, seed=21)
+    w = rnd_bf16(Cout, 3, 3, C, scale=(1.0 / (9 * C)) ** 0.5, seed=22)
+    ref = R.conv2d_fwd(x, w, 1, 1)
+    xd, wd = to_dev_bf16(x), to_dev_bf16(w)
+    y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rows = lib.icamd_conv2d_stats_rows(ctypes.byref(d))
+    stats = torch.full((rows, 2, Cout), float("nan"), device=DEV)
+    assert lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(xd), hip.ptr(wd), hip.ptr(y), None, None, hip.ptr(stats),
+                                hip.stream_ptr()) == 0
+    sync()
+    got = y.float().cpu()
+    assert torch.isfinite(got).all() and R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
+    s1, s2 = R.conv2d_stats(got)
+    st = stats.double().cpu()
+    assert torch.isfinite(st).all()
+    assert torch.allclose(st.sum(0)[0], s1, rtol=1e-4, atol=1e-2) and torch.allclose(st.sum(0)[1], s2, rtol=1e-4, atol=1e-2)
+    # per-row partials: row r covers pixels [128 r, 128 r + 128)
+    flat = got.reshape(-1, Cout).double()
+    for r in (0, rows - 1):
+        assert torch.allclose(st[r, 0], flat[128 * r:128 * r + 128].sum(0), rtol=1e-4, atol=1e-2)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(23))
+    bd = bias.to(DEV)
+    assert lib.icamd_conv2d_fwd_act(ctypes.byref(d), hip.ptr(xd), hip.ptr(wd), hip.ptr(y), hip.ptr(bd), None, 1,
+                                    hip.stream_ptr()) == 0
+    sync()
+    xn, wn_ = R.nhwc_to_nchw(x.float()), w.float().permute(0, 3, 1, 2).contiguous()
+    ref_act = R.bf16_round(torch.relu(R.nchw_to_nhwc(torch.nn.functional.conv2d(xn, wn_, None, 1, 1)) + bias))
+    assert R.rel_l2(y.float().cpu(), ref_act) <= 1e-3
+    if Cout % 64 == 0:   # data gradient (needs the layer's Cout to be a multiple of 64, as icamd_conv2d_dgrad documents)
+        dy = rnd_bf16(N, H, W, Cout, seed=24)
+        w_t = w.permute(3, 1, 2, 0).contiguous()
+        dref = R.conv2d_dgrad(dy, w, (H, W), 1, 1, None)
+        dx = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+        dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w_t)
+        assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), None, None,
+                                      hip.stream_ptr()) == 0
+        sync()
+        gdx = dx.float().cpu()
+        assert torch.isfinite(gdx).all() and R.rel_l2(gdx, dref) <= 1e-3 and R.bf16_close(gdx, dref)
+
+
+@pytest.mark.parametrize("mode", ["2", "3", "0"])
+def test_conv3x3_halo_every_tile_shape(mode):
+    """ICAMD_CONV3X3_HALO: 3 forces the 256-pixel tiles, 2 the 128-pixel tiles, 0 the implicit-GEMM kernel of round 1 (the
+    default picks by problem size): the same cases through each (child process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ICAMD_CONV3X3_HALO=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_conv3x3_halo_fwd_and_dgrad"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0),
                             (4, 14, 14, 256, 256, 3, 1, 1),      # 256x256 ring tile: 9 filter tiles, ragged last stage
                             (3, 9, 9, 512, 256, 1, 1, 0), (2, 14, 14, 256, 512, 3, 2, 1)]
