@@ -49,6 +49,23 @@ class ImageFolder(torch.utils.data.Dataset):
         return (self.transform(img) if self.transform else img), target
 
 
+class RawSubset(torch.utils.data.Dataset):
+    """Decoded but untransformed samples (uint8 HWC arrays) for the GPU input pipeline (gpu_pipeline.py)."""
+
+    def __init__(self, base, indices=None):
+        self.base = base
+        self.indices = list(range(len(base.samples))) if indices is None else list(indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, i):
+        path, target = self.base.samples[self.indices[i]]
+        with open(path, "rb") as f:
+            img = Image.open(f).convert("RGB")
+        return np.asarray(img, dtype=np.uint8), target
+
+
 class _Subset(torch.utils.data.Dataset):
     def __init__(self, base, indices, transform):
         self.base, self.indices, self.transform = base, list(indices), transform
@@ -163,8 +180,20 @@ def _write_class_indices(class_to_idx, output_dir=None):
 
 
 def build_dataset(args):
-    """Returns (train_dataset, val_dataset, num_classes). train_split_rato == 0 -> data_path/train and /val."""
+    """Returns (train_dataset, val_dataset, num_classes). train_split_rato == 0 -> data_path/train and /val.
+    args.gpu_aug: the datasets yield decoded uint8 arrays and the transforms run on the GPU (gpu_pipeline.py)."""
     ratio = getattr(args, "train_split_rato", 0.9)
+    if getattr(args, "gpu_aug", False):
+        if ratio == 0:
+            tr_base, va_base = ImageFolder(os.path.join(args.data_path, "train")), ImageFolder(os.path.join(args.data_path, "val"))
+            _write_class_indices(tr_base.class_to_idx)
+            print("Number of the class = %d" % len(tr_base.classes))
+            return RawSubset(tr_base), RawSubset(va_base), len(tr_base.classes)
+        base = ImageFolder(args.data_path)
+        tr, va = split_dataset(base, ratio)
+        _write_class_indices(base.class_to_idx)
+        print("Number of the class = %d" % len(base.classes))
+        return RawSubset(base, tr), RawSubset(base, va), len(base.classes)
     t_train, t_val = build_transform(True, args), build_transform(False, args)
     if ratio == 0:
         train = ImageFolder(os.path.join(args.data_path, "train"), t_train)

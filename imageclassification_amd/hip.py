@@ -25,6 +25,14 @@ class BnBwdFuse(Structure):
                 ("shift", c_void_p), ("partials", c_void_p), ("relu", c_int)]
 
 
+class ImageDesc(Structure):
+    """include/icamd.h icamd_image_desc (88 bytes)."""
+    _fields_ = [("src_offset", ctypes.c_int64), ("src_h", c_int), ("src_w", c_int), ("crop_top", c_int), ("crop_left", c_int),
+                ("crop_h", c_int), ("crop_w", c_int), ("hflip", c_int), ("vflip", c_int), ("jitter_order", c_int * 3),
+                ("jitter_factor", c_float * 3), ("erase_top", c_int), ("erase_left", c_int), ("erase_h", c_int),
+                ("erase_w", c_int), ("erase_seed", ctypes.c_uint32), ("reserved", c_int)]
+
+
 class ConvDesc(Structure):
     _fields_ = [(n, c_int) for n in ("N", "IH", "IW", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad")]
 
@@ -98,6 +106,10 @@ _SIGNATURES = {
     "icamd_stem7x7s2_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "icamd_stem7x7s2_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "icamd_stem7x7s2_wgrad": (c_int, [_P, _P, _P, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
+    "icamd_image_pipeline_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "icamd_image_pipeline": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _P,
+                                     _P, c_size_t, _P]),
+    "icamd_image_pipeline_u8": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "icamd_softmax_xent": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
     "icamd_step_metrics": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "icamd_grad_norm_workspace_bytes": (c_size_t, []),

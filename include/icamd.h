@@ -243,6 +243,34 @@ size_t icamd_stem7x7s2_wgrad_workspace_bytes(int N, int H, int W, int Cout);
 int icamd_stem7x7s2_wgrad(const void* x4, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
                           int N, int H, int W, int Cout, void* stream);
 
+/* ---- input pipeline on the GPU (replaces the per-sample CPU work of the reference's transforms AFTER JPEG decoding:
+ *      /root/reference/datasets.py:121-144 -- timm.create_transform(scale=(1,1), ratio=(1,1), vflip=0.5, color_jitter=0.3,
+ *      interpolation='bicubic', re_prob=0.25, re_mode='pixel') for training, Resize -> ToTensor -> Normalize for eval;
+ *      loaders train.py:152-170).  Arithmetic = Pillow's (two-pass 8-bit resampling with 22-bit weights, ImageEnhance
+ *      blends, integer luma): bit-exact, tests/test_image_gpu.py.  Random decisions arrive in the descriptors. */
+typedef struct icamd_image_desc {
+  int64_t src_offset;                  /* byte offset of this image's uint8 [src_h][src_w][3] pixels in `src`        */
+  int32_t src_h, src_w;
+  int32_t crop_top, crop_left, crop_h, crop_w;   /* window that is resized to out_h x out_w                          */
+  int32_t hflip, vflip;
+  int32_t jitter_order[3];             /* ColorJitter: operations in application order, 0 brightness / 1 contrast /
+                                          2 saturation, -1 = none                                                     */
+  float jitter_factor[3];              /* factor of operation 0, 1, 2                                                 */
+  int32_t erase_top, erase_left, erase_h, erase_w;   /* RandomErasing box in the output, erase_h = 0: none            */
+  uint32_t erase_seed;                 /* seed of the N(0,1) fill                                                     */
+  int32_t reserved;
+} icamd_image_desc;
+/* kmax: the largest filter window of the batch, ceil(support * max(1, crop / out)) * 2 + 1 with support 2 (bicubic) / 1 */
+size_t icamd_image_pipeline_workspace_bytes(int B, int max_crop_h, int out_h, int out_w, int kmax);
+/* src, descs, out_nchw (fp32 [B][3][out_h][out_w]) and workspace are device pointers; mean3 / std3 are HOST float[3]
+ * (passed on by value).  filter: 0 bilinear, 1 bicubic. */
+int icamd_image_pipeline(const uint8_t* src, const icamd_image_desc* descs, int B, int max_crop_h, int out_h, int out_w,
+                         int filter, int kmax, const float* mean3, const float* std3, float* out_nchw, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* device pointer of the uint8 [B][out_h][out_w][3] image the last call left in `workspace` (after resize, flips and colour
+ * jitter, before ToTensor): what Pillow would hold at that point */
+int icamd_image_pipeline_u8(const void* workspace, int B, int max_crop_h, int out_h, int out_w, int kmax, const uint8_t** img);
+
 /* ---- loss + metrics (criterion engine.py:49,52,178,181; accuracy / TP-FP-FN engine.py:82-97,184-196) ---- */
 /* logits bf16 [B][ld]; targets int64; target distribution lam*onehot_s(y1) + (1-lam)*onehot_s(y2).
  * loss_rows float[B]; pred int32[B] (optional argmax); dlogits bf16 [B][ld] (optional) = (softmax - t)*gscale */

@@ -300,7 +300,7 @@ def test_train_cli_surface_matches_the_reference_parser():
             continue
         want = deliberate.get(k, spec_["default"])
         assert mine[k].default == want, (k, mine[k].default, want)
-    assert sorted(k for k in mine if k not in ref and k != "--help") == ["--num_classes", "--synthetic"]
+    assert sorted(k for k in mine if k not in ref and k != "--help") == ["--gpu_aug", "--num_classes", "--synthetic"]
 
 
 # ---- ConvNeXt oracle pinned to the reference's own definition (tests/golden/make_convnext_fixture.py) ----------------
@@ -400,3 +400,28 @@ def test_checkpoint_model_object_serves_the_reference_consumers_without_a_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(hip.IcamdError):
             got(torch.zeros(1, 3, 32, 32))
+
+
+def test_image_oracle_is_pillow_bit_for_bit():
+    """oracle/image_ref.py (the checker of the GPU input pipeline) against Pillow itself, which the reference's
+    transforms delegate to (datasets.py:121-144 through timm / torchvision on PIL images): two-pass 8-bit resampling (bicubic
+    and bilinear, up- and down-scaling, odd sizes), centre crop, and the three ImageEnhance operations of ColorJitter."""
+    from PIL import Image, ImageEnhance
+    from oracle import image_ref as I
+    rng = np.random.RandomState(0)
+    for (h, w, oh, ow) in [(37, 53, 16, 16), (120, 90, 64, 64), (20, 20, 64, 64), (17, 61, 32, 48), (64, 64, 64, 64), (100, 80, 7, 9)]:
+        a = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        im = Image.fromarray(a)
+        for filt, pf in (("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)):
+            assert np.array_equal(np.asarray(im.resize((ow, oh), pf)), I.resize_u8(a, oh, ow, filt)), (h, w, oh, ow, filt)
+    a = rng.randint(0, 256, (23, 31, 3), dtype=np.uint8)
+    im = Image.fromarray(a)
+    for f in (0.7, 0.85, 1.0, 1.13, 1.3):
+        assert np.array_equal(np.asarray(ImageEnhance.Brightness(im).enhance(f)), I.enhance_brightness(a, f))
+        assert np.array_equal(np.asarray(ImageEnhance.Contrast(im).enhance(f)), I.enhance_contrast(a, f))
+        assert np.array_equal(np.asarray(ImageEnhance.Color(im).enhance(f)), I.enhance_color(a, f))
+    chained = ImageEnhance.Brightness(ImageEnhance.Color(ImageEnhance.Contrast(im).enhance(1.21)).enhance(0.77)).enhance(1.08)
+    assert np.array_equal(np.asarray(chained), I.color_jitter(a, (1, 2, 0), (1.08, 1.21, 0.77)))
+    b = rng.randint(0, 256, (20, 37, 3), dtype=np.uint8)
+    assert np.array_equal(I.center_square(b), np.asarray(Image.fromarray(b).crop((8, 0, 28, 20))))
+    assert np.array_equal(I.center_square(b.transpose(1, 0, 2)), np.asarray(Image.fromarray(b.transpose(1, 0, 2)).crop((0, 8, 20, 28))))

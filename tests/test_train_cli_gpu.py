@@ -72,6 +72,15 @@ def test_train_cli_two_class_imagefolder(tmp_path, monkeypatch):
     import copy
     clone = copy.deepcopy(model)                                                   # timm ModelEmaV3(model) deep-copies it
     assert torch.equal(clone.state_dict()["fc.weight"], model.state_dict()["fc.weight"])
+    # the same recipe with the transforms on the GPU: workers only decode, icamd_image_pipeline does the rest
+    work2 = tmp_path / "work_gpu_aug"
+    os.makedirs(work2 / "train_cls" / "output")
+    monkeypatch.chdir(work2)
+    args_g = T.get_args_parser().parse_args(argv[:-2] + ["--reprob", "0.25", "--gpu_aug", "true", "--auto_resume", "false"])
+    stats_g = T.main(args_g)
+    lines_g = [json.loads(l) for l in open(work2 / "train_cls" / "log.txt")]
+    assert lines_g[-1]["train_loss"] < lines_g[0]["train_loss"] and stats_g["test_acc1"] >= 75.0
+    monkeypatch.chdir(work)
     # auto-resume continues from the latest numbered checkpoint with optimizer state
     args2 = T.get_args_parser().parse_args(argv[:-6] + ["--epochs", "4", "--use_amp", "true", "--reprob", "0"])
     args2.epochs = 4

@@ -70,6 +70,9 @@ def get_args_parser():
     a("--wandb_ckpt", type=str2bool, default=False)
     # additions for the MI355X build
     a("--synthetic", default=0, type=int, help="use N seeded random images instead of --data_path")
+    a("--gpu_aug", type=str2bool, default=False,
+      help="run the transforms of datasets.py (resize, flips, colour jitter, normalise, random erasing) as HIP kernels on the "
+           "decoded uint8 images instead of per sample on the host (imageclassification_amd/gpu_pipeline.py)")
     a("--num_classes", default=1000, type=int, help="classes of the synthetic dataset")
     return p
 
@@ -106,10 +109,22 @@ def main(args):
         sampler_train = torch.utils.data.DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank,
                                                             shuffle=True, seed=args.seed)
     sampler_val = torch.utils.data.SequentialSampler(dataset_val)
-    data_loader_train = torch.utils.data.DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size,
-                                                    num_workers=args.num_workers, pin_memory=True, drop_last=True)
-    data_loader_val = torch.utils.data.DataLoader(dataset_val, sampler=sampler_val, batch_size=int(1.5 * args.batch_size),
-                                                  num_workers=args.num_workers, pin_memory=True)
+    gpu_aug = bool(getattr(args, "gpu_aug", False)) and not args.synthetic
+    if gpu_aug:   # workers only decode; the transforms run on the device, one C-ABI call per batch
+        from imageclassification_amd.gpu_pipeline import GpuAugmentLoader, GpuImagePipeline, raw_collate
+        data_loader_train = GpuAugmentLoader(
+            torch.utils.data.DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size,
+                                        num_workers=args.num_workers, drop_last=True, collate_fn=raw_collate),
+            GpuImagePipeline(args.input_size, True, args.color_jitter, args.reprob, device=str(device)))
+        data_loader_val = GpuAugmentLoader(
+            torch.utils.data.DataLoader(dataset_val, sampler=sampler_val, batch_size=int(1.5 * args.batch_size),
+                                        num_workers=args.num_workers, collate_fn=raw_collate),
+            GpuImagePipeline(args.input_size, False, device=str(device)))
+    else:
+        data_loader_train = torch.utils.data.DataLoader(dataset_train, sampler=sampler_train, batch_size=args.batch_size,
+                                                        num_workers=args.num_workers, pin_memory=True, drop_last=True)
+        data_loader_val = torch.utils.data.DataLoader(dataset_val, sampler=sampler_val, batch_size=int(1.5 * args.batch_size),
+                                                      num_workers=args.num_workers, pin_memory=True)
     input_shape = [1, 3, args.input_size, args.input_size]
 
     mixup_fn = None
