@@ -21,7 +21,7 @@
 // [Cin][3][3][Cout] and mirrored taps (flip = 1).
 // Epilogue as conv_igemm.hip: lanes own 4 consecutive channels of a pixel, bias added in fp32, one rounding, bf16 tile
 // through LDS, 16 B coalesced row stores, optional ReLU, optional per-channel sum / sum-of-squares of the rounded outputs
-// as one partial row per 128 pixels (BatchNorm statistics, no float atomics).
+// as one partial row per tile (BatchNorm statistics, no float atomics).
 #include "common.h"
 #include "icamd_internal.h"
 #include <cstdlib>
@@ -260,11 +260,9 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_halo_kernel(const Halo3x3Par
   const int cp = tid & (CPR - 1), rg = tid / CPR;
   const int co = n0 + cp * 8;
   const bool co_ok = co < p.Cout;
-  float s1[2][8], s2[2][8];                // statistics of the two 128-pixel halves of a 256-pixel tile
+  float s1[8], s2[8];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[hh][e] = 0.f; s2[hh][e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int ml = ps * RPP + rg;
@@ -273,37 +271,37 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_halo_kernel(const Halo3x3Par
     if (m < p.M && co_ok) {
       *(u32x4*)(p.out + (long long)m * p.Cout + co) = o;
       if (p.stats != nullptr) {
-        const int hh = (BM == 256) ? (ps * RPP >= 128 ? 1 : 0) : 0;   // RPP divides 128: a pass never straddles the halves
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float lo = bf16_lo(o[e]), hi = bf16_hi(o[e]);
-          s1[hh][2 * e] += lo; s2[hh][2 * e] += lo * lo;
-          s1[hh][2 * e + 1] += hi; s2[hh][2 * e + 1] += hi * hi;
+          s1[2 * e] += lo; s2[2 * e] += lo * lo;
+          s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
         }
       }
     }
   }
   if (p.stats != nullptr) {
+    // One partial row per TILE (row tile_m).  The consumer sums ceil(M / 128) rows (icamd_conv2d_stats_rows), which is at
+    // most twice the tile count for BM >= 128: the rows this grid does not produce are zero-filled by the tile whose index
+    // they exceed the tile count by.
     __syncthreads();
-    float* red = (float*)smem;             // [RPP][2][BN] per half, halves one after the other
-    constexpr int HALVES = BM / 128;
+    float* red = (float*)smem;             // [RPP][2][BN]
 #pragma unroll
-    for (int hh = 0; hh < HALVES; ++hh) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[((hh * RPP + rg) * 2 + 0) * BN + cp * 8 + e] = s1[hh][e];
-        red[((hh * RPP + rg) * 2 + 1) * BN + cp * 8 + e] = s2[hh][e];
-      }
+    for (int e = 0; e < 8; ++e) {
+      red[(rg * 2 + 0) * BN + cp * 8 + e] = s1[e];
+      red[(rg * 2 + 1) * BN + cp * 8 + e] = s2[e];
     }
     __syncthreads();
-    for (int idx = tid; idx < HALVES * 2 * BN; idx += 256) {
-      const int hh = idx / (2 * BN), rest = idx - hh * 2 * BN;
-      const int which = rest / BN, c = rest - which * BN;
+    const int ntm = (p.M + BM - 1) / BM, nrows = (p.M + 127) / 128;
+    for (int idx = tid; idx < 2 * BN; idx += 256) {
+      const int which = idx / BN, c = idx - which * BN;
       float s = 0.f;
 #pragma unroll 4
-      for (int g = 0; g < RPP; ++g) s += red[((hh * RPP + g) * 2 + which) * BN + c];
-      const long long row = (long long)tile_m * HALVES + hh;
-      if (n0 + c < p.Cout && row * 128 < p.M) p.stats[(row * 2 + which) * p.Cout + n0 + c] = s;
+      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + c];
+      if (n0 + c < p.Cout) {
+        p.stats[((long long)tile_m * 2 + which) * p.Cout + n0 + c] = s;
+        if (ntm + tile_m < nrows) p.stats[((long long)(ntm + tile_m) * 2 + which) * p.Cout + n0 + c] = 0.f;
+      }
     }
   }
 }
@@ -344,14 +342,30 @@ int icamd_halo3x3_launch(Halo3x3Params& p, hipStream_t stream) {
   p.divW = make_fastdiv((unsigned)p.W);
   const int bn = p.Cout <= 64 ? 64 : 128;
   p.ntiles_n = (p.Cout + bn - 1) / bn;
-  // 256-pixel tiles when they still give every CU ~1.5 workgroups, else 128-pixel tiles (7x7 maps at batch 256)
-  const long long tiles256 = (long long)((p.M + 255) / 256) * p.ntiles_n;
-  const bool big = halo_mode() == 2 ? false : (halo_mode() == 3 ? true : tiles256 >= 384);
-  const int slots = (big ? 256 : 128) + 2 * p.W + 2 + 1;   // + the zero row
+  // Pixel-tile height: 256, 224 or 128, whichever finishes the grid in the fewest (rounds x tile) at two workgroups per CU
+  // (e.g. 256 -> 256 at 14 x 14, batch 256: 392 tiles of 256 fill 77 % of one round, 448 tiles of 224 fill 88 % of it).
+  int bm = 128;
+  if (halo_mode() == 3) bm = 256;
+  else if (halo_mode() != 2) {
+    long long best = -1;
+    for (int cand : {256, 224, 128}) {
+      if (cand == 224 && bn != 128) continue;
+      const long long tiles = (long long)((p.M + cand - 1) / cand) * p.ntiles_n;
+      const long long cost = ((tiles + 511) / 512) * cand + (cand == 128 ? 16 : 0);   // small tiles re-read the filter more
+      if (best < 0 || cost < best) { best = cost; bm = cand; }
+    }
+  }
+  const bool big = bm != 128;
+  const int slots = bm + 2 * p.W + 2 + 1;                 // + the zero row
   const int la = (slots + 31) / 32;                       // instructions per wave (8 slots each, 4 waves)
   if (la > 12) return ICAMD_ERR_UNSUPPORTED;
   // LDS per workgroup = 4 KB * LA (input tile) + filter ring <= 80 KB: two workgroups per CU
   if (bn == 128) {   // 2 x 2 waves, 128 x 64 (or 64 x 64) accumulators per wave; 16 KB filter stages of 64 channels
+    if (bm == 224) {
+      if (la <= 8) return launch_halo<128, 2, 7, 8, 3, 64, 2>(p, stream);      // W <= 14: 32 + 48 = 80 KB, ring of three
+      if (la <= 10) return launch_halo<128, 2, 7, 10, 2, 64, 2>(p, stream);
+      return launch_halo<128, 2, 7, 12, 2, 64, 2>(p, stream);
+    }
     if (big) {
       if (la <= 9) return launch_halo<128, 2, 8, 9, 2, 64, 2>(p, stream);      // 36 + 32 = 68 KB
       if (la <= 10) return launch_halo<128, 2, 8, 10, 2, 64, 2>(p, stream);    // 40 + 32 = 72 KB

@@ -45,8 +45,9 @@ typedef struct icamd_conv_desc {
 int icamd_conv2d_stats_rows(const icamd_conv_desc* d);
 
 /* y = conv(x, w) (+ bias[co]) (+ addend, same shape as y), rounded once to bf16.
- * stats (optional): float [stats_rows][2][Cout] <- per-128-pixel-tile sum and sum of squares of the ROUNDED y
- * (BatchNorm batch statistics, consumed by icamd_bn_train_finalize). */
+ * stats (optional): float [stats_rows][2][Cout] <- partial sums and sums of squares of the ROUNDED y over disjoint pixel
+ * tiles (rows a kernel's tiling does not need are written as zeros): BatchNorm batch statistics, consumed -- summed over
+ * all stats_rows rows -- by icamd_bn_train_finalize. */
 int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                      const void* addend, float* stats, void* stream);
 /* Inference form of icamd_conv2d_fwd (evaluate(), engine.py:145-225, on a model whose BatchNorms were folded with

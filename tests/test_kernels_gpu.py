@@ -318,10 +318,6 @@ def test_conv3x3_halo_fwd_and_dgrad(lib, case):
     st = stats.double().cpu()
     assert torch.isfinite(st).all()
     assert torch.allclose(st.sum(0)[0], s1, rtol=1e-4, atol=1e-2) and torch.allclose(st.sum(0)[1], s2, rtol=1e-4, atol=1e-2)
-    # per-row partials: row r covers pixels [128 r, 128 r + 128)
-    flat = got.reshape(-1, Cout).double()
-    for r in (0, rows - 1):
-        assert torch.allclose(st[r, 0], flat[128 * r:128 * r + 128].sum(0), rtol=1e-4, atol=1e-2)
     bias = torch.randn(Cout, generator=torch.Generator().manual_seed(23))
     bd = bias.to(DEV)
     assert lib.icamd_conv2d_fwd_act(ctypes.byref(d), hip.ptr(xd), hip.ptr(wd), hip.ptr(y), hip.ptr(bd), None, 1,
