@@ -235,12 +235,13 @@ int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta,
 }
 
 static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
-                      const uint8_t* addend_bits, const icamd_bn_bwd_fuse* f, void* stream, const void* gelu_z = nullptr) {
+                      const uint8_t* addend_bits, const icamd_bn_bwd_fuse* f, void* stream, const void* gelu_z = nullptr,
+                      int addend_sub2 = 0) {
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || dx == nullptr) return ICAMD_ERR_BAD_ARG;
   if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
-  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && addend_bits == nullptr && f == nullptr &&
+  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && addend_bits == nullptr && f == nullptr && !addend_sub2 &&
       icamd_gemm_nt_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
@@ -269,6 +270,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
       p.in = (const bf16_t*)dy; p.wt = (const bf16_t*)w_t; p.out = (bf16_t*)dx;
       p.addend = (const bf16_t*)addend;
       p.addend_bits = addend_bits;
+      p.addend_sub2 = addend_sub2;
       p.gelu_z = (const bf16_t*)gelu_z;
       p.N = d->N; p.IH = d->OH; p.IW = d->OW; p.Cin = d->Cout;
       p.OH = d->IH; p.OW = d->IW; p.Cout = d->Cin;
@@ -306,6 +308,13 @@ int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
   if (addend_maskbits != nullptr && (addend == nullptr || d == nullptr || d->Cin % 64 != 0)) return ICAMD_ERR_BAD_ARG;
   return dgrad_impl(d, dy, w_t, dx, addend, addend_maskbits, nullptr, stream);
+}
+
+int icamd_conv2d_dgrad_sub2(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend_sub2,
+                            void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  if (addend_sub2 == nullptr) return ICAMD_ERR_BAD_ARG;
+  return dgrad_impl(d, dy, w_t, dx, addend_sub2, nullptr, nullptr, stream, nullptr, 1);
 }
 
 int icamd_conv2d_dgrad_gelu(const icamd_conv_desc* d, const void* dy, const void* w_t, const void* z, void* dz,

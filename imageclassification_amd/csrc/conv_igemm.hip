@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
   {
     const bool has_addend = p.addend != nullptr;   // wave-uniform
     int moff[4];
+    unsigned long long abw[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       moff[i] = 0;   // rows past M read pixel 0 (valid memory); their results are never stored
@@ -273,11 +274,16 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         const unsigned int rem = m - n * (p.P * p.Q);
         const unsigned int pp = fdiv(rem, p.divQ);
         const unsigned int qq = rem - pp * p.Q;
-        moff[i] = ((n * p.OH + pp * p.ostr + p.ooff_h) * p.OW + qq * p.ostr + p.ooff_w) * p.Cout;
+        const unsigned int oh = pp * p.ostr + p.ooff_h, ow = qq * p.ostr + p.ooff_w;
+        if (p.addend_sub2) {   // addend lives on the even pixel grid only (gradient sent back by a 1x1 stride-2 shortcut)
+          if ((oh | ow) & 1u) abw[i] = 0ull;
+          else moff[i] = ((n * ((p.OH + 1) >> 1) + (oh >> 1)) * ((p.OW + 1) >> 1) + (ow >> 1)) * p.Cout;
+        } else {
+          moff[i] = ((n * p.OH + oh) * p.OW + ow) * p.Cout;
+        }
       }
     }
     // ReLU-mask bits of the addend: the wave's BN/2 channels of one pixel are BN/16 consecutive bytes -> one load per row
-    unsigned long long abw[4] = {~0ull, ~0ull, ~0ull, ~0ull};
     if (has_addend && p.addend_bits != nullptr) {
       const int cw0 = n0 + wn * (BN / 2);
       const int cwc = cw0 < p.Cout ? cw0 : 0;

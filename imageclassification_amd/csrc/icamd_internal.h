@@ -12,6 +12,7 @@ struct IgemmParams {
   bf16_t* out;
   const bf16_t* addend;  // optional, laid out like out
   const unsigned char* addend_bits;  // optional 1 bit per addend element: the addend counts only where its bit is set
+  int addend_sub2;       // 1: addend is [N][ceil(OH/2)][ceil(OW/2)][Cout], added at even (oh, ow) only; others get none
   const float* bias;     // optional [Cout]
   float* stats;          // optional [ceil(M/128)][2][Cout] partial sum / sum-of-squares of rounded outputs
   // fused BatchNorm-backward pass 1 (data-gradient launches only; enabled by bnb_y != nullptr)

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "icamd_conv2d_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "icamd_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "icamd_conv2d_dgrad_sub2": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "icamd_conv2d_dgrad_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, POINTER(BnBwdFuse), _P]),
     "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),

@@ -27,6 +27,7 @@ BN_EPS = 1e-5
 _FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
 _WGRAD_STREAM = os.environ.get("ICAMD_WGRAD_STREAM", "1") != "0"
 _DUAL_BNBWD = os.environ.get("ICAMD_DUAL_BNBWD", "1") != "0"
+_SUB2_SHORTCUT = os.environ.get("ICAMD_SUB2_SHORTCUT", "1") != "0"
 BN_MOMENTUM = 0.1
 
 ARCHS = {
@@ -774,9 +775,25 @@ class ResNet(PicklableModel):
                 if y2 is None:
                     y2 = next_y()
                     bn_bwd(blk["down_bn"], dout, None, b["yd"], ypool[y2], None, True, mask)   # "relu" = the block's mask bits
-                wgrad(blk["down_conv"], xin.data_ptr(), ypool[y2], N, h, w, ybuf=y2)
-                dgrad(blk["down_conv"], ypool[y2], T, None, N, h, w)
-                dgrad(convs[0], ypool[yk], other, T, N, h, w)
+                dc = blk["down_conv"]
+                wgrad(dc, xin.data_ptr(), ypool[y2], N, h, w, ybuf=y2)
+                if _SUB2_SHORTCUT and dc.k == 1 and dc.stride == 2 and dc.pad == 0:
+                    # a 1x1 stride-2 shortcut sends gradient to the even pixels only: compute it on the [OH][OW] grid (a
+                    # plain pointwise data gradient) and let the main branch's data gradient add it there
+                    # (icamd_conv2d_dgrad_sub2); the 3/4 zeros of the full-size tensor are never written or read
+                    dd = dc.desc(N, h, w)
+                    key = ("sub2", N, dd.OH, dd.OW)
+                    d1 = dc.descs.get(key)
+                    if d1 is None:
+                        d1 = dc.descs[key] = hip.conv_desc(N, dd.OH, dd.OW, dc.cin_p, dc.cout_p, 1, 1, 1, 0)
+                    hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d1), ypool[y2], self._wt(dc), T, None, None, s),
+                              dc.name + " dgrad (even grid)")
+                    d0 = convs[0].desc(N, h, w)
+                    hip.check(lib.icamd_conv2d_dgrad_sub2(ctypes.byref(d0), ypool[yk], self._wt(convs[0]), other, T, s),
+                              convs[0].name + " dgrad + shortcut")
+                else:
+                    dgrad(dc, ypool[y2], T, None, N, h, w)
+                    dgrad(convs[0], ypool[yk], other, T, N, h, w)
             else:
                 dgrad(convs[0], ypool[yk], other, dout, N, h, w, mask)
             if hook:

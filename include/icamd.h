@@ -72,6 +72,13 @@ int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta,
  * "output gradient x ReLU mask" without that product ever being materialised. */
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
                        const uint8_t* addend_maskbits, void* stream);
+/* Same, with an addend that exists on the EVEN pixel grid only: addend_sub2 is [N][ceil(IH/2)][ceil(IW/2)][Cin] and is
+ * added to dx[n][2p][2q][:]; every other pixel gets no addend.  This is the gradient a 1x1 stride-2 shortcut convolution
+ * (ResNet downsample, /root/reference/models/ -> torchvision resnet `downsample`) sends back to the block input:
+ * compute it as the stride-1 data gradient on the [N][OH][OW] grid and hand it over here; the 3/4 of the full-size
+ * tensor that would be zeros is never written or read. */
+int icamd_conv2d_dgrad_sub2(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend_sub2,
+                            void* stream);
 
 /* Mlp fc2 data gradient with the GELU backward fused into the store pass: dz = bf16(conv_transpose(dy, w)) * gelu'(z),
  * z shaped like dz (bit-identical to icamd_conv2d_dgrad followed by icamd_gelu_bwd; the gradient of the GELU output is

@@ -1056,6 +1056,35 @@ def test_conv_dgrad_addend_maskbits(lib):
                                   hip.stream_ptr()) == 1      # bits without an addend: bad argument
 
 
+@pytest.mark.parametrize("case", [(2, 10, 9, 128, 64, 1, 1, 0), (2, 12, 12, 256, 128, 1, 1, 0), (2, 9, 11, 64, 64, 3, 2, 1),
+                                  (1, 8, 8, 512, 256, 1, 1, 0)])
+def test_conv_dgrad_addend_on_even_grid(lib, case):
+    """icamd_conv2d_dgrad_sub2 == icamd_conv2d_dgrad with the compact addend scattered into a zero tensor (bit for bit),
+    and both match the oracle: the gradient a 1x1 stride-2 shortcut sends back exists on the even pixels only."""
+    hip = _hip()
+    N, H, W, Cin, Cout, k, st, pad = case
+    d = hip.conv_desc(N, H, W, Cin, Cout, k, k, st, pad)
+    dy = rnd_bf16(N, d.OH, d.OW, Cout, seed=94)
+    w = rnd_bf16(Cout, k, k, Cin, scale=0.1, seed=95)
+    ah, aw = (H + 1) // 2, (W + 1) // 2
+    compact = rnd_bf16(N, ah, aw, Cin, seed=96)
+    full = torch.zeros(N, H, W, Cin)
+    full[:, ::2, ::2, :] = compact
+    ref = R.conv2d_dgrad(dy, w, (H, W), st, pad, full)
+    dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w.permute(3, 1, 2, 0).contiguous())
+    cd, fd = to_dev_bf16(compact), to_dev_bf16(full)
+    dx1 = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+    dx2 = torch.empty_like(dx1)
+    s = hip.stream_ptr()
+    assert lib.icamd_conv2d_dgrad_sub2(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx1), hip.ptr(cd), s) == 0
+    assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx2), hip.ptr(fd), None, s) == 0
+    sync()
+    got = dx1.float().cpu()
+    assert R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
+    assert torch.equal(dx1, dx2)
+    assert lib.icamd_conv2d_dgrad_sub2(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx1), None, s) == 1
+
+
 @pytest.mark.parametrize("rows,C", [(50, 768), (197 * 3, 768), (64, 96), (33, 384), (5, 1024)])
 def test_layernorm_fwd_bwd(lib, rows, C):
     hip = _hip()
