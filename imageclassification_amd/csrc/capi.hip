@@ -241,12 +241,13 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
   if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
-  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && addend_bits == nullptr && f == nullptr && !addend_sub2 &&
+  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && addend_bits == nullptr && f == nullptr &&
       icamd_gemm_nt_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.addend = (const bf16_t*)addend;
     g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout; g.gelu_z = (const bf16_t*)gelu_z;
+    if (addend_sub2) { g.sub2_h = d->IH; g.sub2_w = d->IW; }
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
   }
   if (d->KH == 3 && d->KW == 3 && st == 1 && d->pad == 1 && addend == nullptr && addend_bits == nullptr && f == nullptr &&

@@ -167,6 +167,24 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
   __syncthreads();   // all fragment reads done: the ring becomes the output tile
 
   // ---- epilogue: MFMA layout -> bias/addend -> bf16 -> LDS [256][TN] (chunk ^= row & (CPR-1)) -> coalesced rows ----
+  long long aoff[8];      // addend row offsets of this lane's 8 rows; < 0: the row has no addend
+  if (p.addend != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ml = wm * 128 + i * 16 + fr;
+      const unsigned int mr = (m0 + ml < p.M) ? m0 + ml : 0;
+      if (p.sub2_h > 0) {   // addend on the even pixel grid only (see icamd_conv2d_dgrad_sub2)
+        const unsigned int n = fdiv(mr, p.divHW);
+        const unsigned int rem = mr - n * (p.sub2_h * p.sub2_w);
+        const unsigned int hh = fdiv(rem, p.divW);
+        const unsigned int ww = rem - hh * p.sub2_w;
+        const long long r = ((long long)n * ((p.sub2_h + 1) >> 1) + (hh >> 1)) * ((p.sub2_w + 1) >> 1) + (ww >> 1);
+        aoff[i] = ((hh | ww) & 1u) ? -1 : r * p.N;
+      } else {
+        aoff[i] = (long long)mr * p.N;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int cl = wn * 64 + j * 16 + 4 * fq;
@@ -178,9 +196,8 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
     for (int i = 0; i < 8; ++i) {
       const int ml = wm * 128 + i * 16 + fr;
       f32x4 v = acc[j][i] + b4;
-      if (p.addend != nullptr) {
-        const int mr = (m0 + ml < p.M) ? m0 + ml : 0;
-        const u32x2 a = *(const u32x2*)(p.addend + (long long)mr * p.N + cgc);
+      if (p.addend != nullptr && aoff[i] >= 0) {
+        const u32x2 a = *(const u32x2*)(p.addend + aoff[i] + cgc);
         v[0] += bf16_lo(a[0]); v[1] += bf16_hi(a[0]); v[2] += bf16_lo(a[1]); v[3] += bf16_hi(a[1]);
       }
       if (p.relu) {
@@ -232,6 +249,10 @@ int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream) {
   if (p.K % TK != 0 || p.N % 8 != 0 || p.M <= 0) return ICAMD_ERR_UNSUPPORTED;
   const int tn = tile_n_width();
   p.ntiles_n = (p.N + tn - 1) / tn;
+  if (p.sub2_h > 0) {
+    p.divHW = make_fastdiv((unsigned)(p.sub2_h * p.sub2_w));
+    p.divW = make_fastdiv((unsigned)p.sub2_w);
+  }
   const long long tiles = (long long)((p.M + TM - 1) / TM) * p.ntiles_n;
   if (tn == 256) hipLaunchKernelGGL(gemm_nt_kernel<256>, dim3((unsigned)tiles), dim3(512), 0, stream, p);
   else hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, stream, p);

@@ -63,6 +63,8 @@ struct GemmNtParams {
   const bf16_t* addend;  // optional [M][N]
   const float* bias;     // optional [N]
   int M, N, K;
+  int sub2_h, sub2_w;    // > 0: rows are pixels of [.][sub2_h][sub2_w]; addend is [.][ceil(h/2)][ceil(w/2)][N], added at even (h, w)
+  FastDiv divHW, divW;   // filled by the launcher when sub2_h > 0
   int relu;              // clamp at zero before rounding
   bf16_t* gelu_out;      // optional second output [M][N]: gelu(rounded out)
   int gelu_inplace;      // out itself receives gelu(rounded result)

@@ -1085,6 +1085,24 @@ def test_conv_dgrad_addend_on_even_grid(lib, case):
     assert lib.icamd_conv2d_dgrad_sub2(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx1), None, s) == 1
 
 
+def test_conv_dgrad_addend_on_even_grid_large_tile_gemm():
+    """The same through gemm_nt.hip (ICAMD_GEMM_NT=2 routes every pointwise problem there; read once per process)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_kernels_gpu as T\n"
+        "from imageclassification_amd import hip\n"
+        "lib = hip.load()\n"
+        "for case in [(2, 10, 9, 128, 64, 1, 1, 0), (2, 12, 12, 256, 128, 1, 1, 0), (3, 7, 7, 512, 256, 1, 1, 0)]:\n"
+        "    T.test_conv_dgrad_addend_on_even_grid(lib, case)\n"
+        "print('forced-ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ICAMD_GEMM_NT="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("rows,C", [(50, 768), (197 * 3, 768), (64, 96), (33, 384), (5, 1024)])
 def test_layernorm_fwd_bwd(lib, rows, C):
     hip = _hip()
