@@ -33,8 +33,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+// Two conversions in ONE v_cvt_pk_bf16_f32 (the scalar form costs two converts and an OR per pair); same rounding.
+typedef __bf16 icamd_bf16x2_hw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  typedef float icamd_f32x2_t __attribute__((ext_vector_type(2)));
+  const icamd_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, icamd_bf16x2_hw));
 }
 __device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }

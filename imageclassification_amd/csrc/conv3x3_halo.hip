@@ -306,6 +306,274 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_halo_kernel(const Halo3x3Par
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels (ResNet layer1 conv2; every BasicBlock convolution of ResNet-18/34 at 56 x 56): the whole filter is
+// 64 x 576 bf16 = 72 KB.  A wave that owns HALF of the output channels needs 18 k-steps x 2 channel fragments x 4 VGPRs =
+// 144 registers for its half, so every wave keeps its filter half in REGISTERS for the life of the kernel and the
+// workgroups are PERSISTENT (two per CU, tiles b, b + grid, ...):
+//   * nothing but the input halo tile goes through LDS: 128 + 2W + 2 slots of 128 B per 128-pixel tile, double-buffered,
+//     the next tile's LDS-DMA in flight under the current tile's MFMAs; the filter operand costs no LDS reads and no L2
+//     traffic after the first microseconds (the implicit-GEMM kernel re-gathers the input per tap and re-reads the filter
+//     per tile: 7x the L2 -> LDS bytes);
+//   * four waves = 2 pixel halves x 2 channel halves, 64 pixels x 32 channels of accumulators per wave; one s_barrier per
+//     tile; the epilogue (MFMA layout -> 64 B half rows through a wave-private LDS patch, row stores, BatchNorm partial
+//     sums in registers) has no workgroup barrier, and the second workgroup of the CU runs its MFMAs meanwhile;
+//   * BatchNorm statistics leave as ONE partial row per workgroup (the rows of the [ceil(M/128)] table that no workgroup
+//     owns are zero-filled).
+// ACT: bias / ReLU epilogue of the inference form (icamd_conv2d_fwd_act); the training form carries neither.
+template <bool ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_resident_kernel(const Halo3x3Params p, const int ntiles) {
+  constexpr int BM = 128, LA = 8;
+  constexpr int A_BYTES = 32 * LA * 128;       // 256 slots; slot 255 is staged from the zero page
+  constexpr int E_BYTES = 4 * 64 * 64;
+  constexpr int ZERO_SLOT = 32 * LA - 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + E_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int W = p.W, H = p.H;
+  const bf16_t* __restrict__ in = p.in;
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+  unsigned char* const sE = smem + 2 * A_BYTES + wave * 4096;
+  const unsigned lds_base = (unsigned)(uintptr_t)LPTR(smem);
+
+  // ---- this wave's filter half, once: fragment (k-step ks = tap*2 + half, channel fragment j): row wn*32 + j*16 + fr
+  bf16x8 wf[18][2];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) {
+    const int tap = ks >> 1;
+    const int wtap = p.flip ? 8 - tap : tap;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      wf[ks][j] = *(const bf16x8*)(p.wt + ((wn * 32 + j * 16 + fr) * 9 + wtap) * 64 + (ks & 1) * 32 + fq * 8);
+  }
+  // The filter must have ARRIVED before the tile loop: left to the compiler, its s_waitcnt vmcnt(0) would sit at the first
+  // use inside the loop, behind the next tile's LDS-DMA, and drain that every tile.  (The builtin, not inline asm: the
+  // compiler's wait-count bookkeeping sees it.)  simm16 = vmcnt 0, expcnt 7, lgkmcnt 15.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  // Staging: instruction j of wave w covers slots (j*4 + w)*8 .. +7 (1 KiB of LDS); slot s holds pixel m0 - (W+1) + s with
+  // its 16 B chunks rotated by s & 7 -- and s & 7 is lane >> 3 for every instruction, so a lane's source is one pointer
+  // advanced by 32 pixels per instruction.
+  const int a_slot = wave * 8 + (lane >> 3);
+  const int a_lc = (((lane & 7) - (lane >> 3)) & 7) * 8;
+  const bool a_zero_lane = a_slot == 31;       // in the last instruction: slot 255, the zero row
+  auto stage_a = [&](int m0, unsigned char* dst) {
+    const int pix0 = m0 - (W + 1) + a_slot;
+    const bf16_t* src0 = in + ((long long)pix0 * 64 + a_lc);
+    if (m0 - (W + 1) >= 0 && m0 - (W + 1) + LA * 32 <= p.M) {   // uniform: every tile but the tensor's first and last ones
+#pragma unroll
+      for (int j = 0; j < LA; ++j) {
+        const bf16_t* src = src0 + j * (32 * 64);
+        if (j == LA - 1) src = a_zero_lane ? zero : src;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < LA; ++j) {
+        const int pix = pix0 + j * 32;
+        const bf16_t* src = (pix >= 0 && pix < p.M && !(j == LA - 1 && a_zero_lane)) ? src0 + j * (32 * 64) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x2 s1[4], s2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
+
+  int buf = 0;
+  int tile = blockIdx.x;
+  if (tile < ntiles) stage_a(tile * BM, smem);
+  halo_wait_vmcnt<0>();        // the first tile has no stores behind its loads: the counted wait below would let it through
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const int m0 = tile * BM;
+    // this tile's input has landed for every wave, and every wave is done reading the other buffer (previous tile).
+    // (in flight behind the input loads: the previous tile's 4 row stores -- every tile but a workgroup's LAST has all
+    // 128 rows, so exactly 4 store instructions per wave follow the loads this wait is for)
+    halo_wait_vmcnt<4>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + (int)gridDim.x < ntiles) stage_a((tile + gridDim.x) * BM, smem + (buf ^ 1) * A_BYTES);
+
+    // ---- per-lane pixel state of the four fragments: (h, w) of pixel m0 + wm*64 + i*16 + fr; tap validity as lane masks:
+    // rows x columns.
+    // W % 8 == 0 (launcher), so the chunk rotation (fq + slot) & 7 does not depend on the tap's ROW: three addresses per
+    // fragment (columns -1, 0, +1) at tap row -1; the tap row adds dh * W * 128 bytes.
+    const unsigned sa = lds_base + (unsigned)(buf * A_BYTES);
+    const unsigned zaddr = sa + (unsigned)(ZERO_SLOT * 128);
+    // Fragment i sits 16 slots = 2048 B behind fragment 0 with the SAME rotation (16 = 0 mod 8): its reads are fragment 0's
+    // address with an immediate offset of i * 2048, so three addresses serve all four fragments; lanes whose tap leaves the
+    // image take the zero row's address minus that offset instead.
+    unsigned abase[3];
+    bool hv0[4], hv2[4], wv0[4], wv2[4];
+    {
+      const int ml0 = wm * 64 + fr;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int sl = ml0 + d;                  // slot of (row -1, column d-1): centre slot ml + W + 1, minus W, plus d - 1
+        abase[d] = sa + (unsigned)((sl << 7) | (((fq + sl) & 7) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned int m = (unsigned)(m0 + ml0 + i * 16);
+        if (m >= (unsigned)p.M) m = 0;           // rows past M are never stored; any in-range pixel will do
+        const unsigned int n = fdiv(m, p.divHW);
+        const unsigned int rem = m - n * (H * W);
+        const int h = (int)fdiv(rem, p.divW);
+        const int w = (int)(rem - (unsigned)h * W);
+        hv0[i] = h > 0; hv2[i] = h + 1 < H; wv0[i] = w > 0; wv2[i] = w + 1 < W;
+      }
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A-fragment reads as inline asm: hipcc's waitcnt pass would otherwise put s_waitcnt vmcnt(0) in front of every C++ LDS
+    // load while the next tile's LDS-DMA is in flight (it cannot tell the two buffers apart).  Completion is waited for by
+    // hand; the fragments of k-step ks+1 are requested before the 8 MFMAs of k-step ks.
+    bf16x8 xf[2][4];
+    unsigned aaddr[4];
+    auto tap_addresses = [&](int tap) {
+      const int dh = tap / 3, dw = tap % 3;      // 0, 1, 2 = -1, 0, +1
+      const unsigned t = abase[dw] + (unsigned)(dh * W * 128);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool okh = dh == 0 ? hv0[i] : (dh == 2 ? hv2[i] : true);
+        const bool okw = dw == 0 ? wv0[i] : (dw == 2 ? wv2[i] : true);
+        aaddr[i] = (okh && okw) ? t : zaddr - (unsigned)(i * 2048);
+      }
+    };
+#define ICAMD_READ4(dst, X)                                                                      \
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(aaddr[0] ^ (X)));                      \
+  asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dst[1]) : "v"(aaddr[1] ^ (X)));          \
+  asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(dst[2]) : "v"(aaddr[2] ^ (X)));          \
+  asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(dst[3]) : "v"(aaddr[3] ^ (X)));
+    tap_addresses(0);
+    ICAMD_READ4(xf[0], 0u)
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+      // the wait names the four fragments as in/out operands: their consumers cannot be scheduled above it
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(xf[ks & 1][0]), "+v"(xf[ks & 1][1]), "+v"(xf[ks & 1][2]), "+v"(xf[ks & 1][3])::"memory");
+      if (ks + 1 < 18) {
+        if (((ks + 1) & 1) == 0) {
+          tap_addresses((ks + 1) >> 1);
+          ICAMD_READ4(xf[(ks + 1) & 1], 0u)
+        } else {
+          ICAMD_READ4(xf[(ks + 1) & 1], 64u)     // second 32-channel half: chunk position bit 2 flipped
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);         // the next reads are in flight BEFORE this k-step's MFMAs
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[ks & 1][i], acc[j][i], 0, 0, 0);
+    }
+#undef ICAMD_READ4
+
+    // ---- epilogue, wave-private: MFMA layout -> [bias, relu] -> bf16 -> this wave's [64 px][32 ch] LDS patch (64 B rows,
+    // 16 B chunk ^= (row >> 2) & 3) -> 64 B half-row stores
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (ACT) {
+        if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + wn * 32 + j * 16 + 4 * fq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pl = i * 16 + fr;
+        f32x4 v = acc[j][i];
+        if constexpr (ACT) {
+          v += b4;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+          }
+        }
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        const int slot = j * 4 + fq;              // 8 B slot of the 64 B row; 16 B chunk = slot >> 1
+        *(u32x2*)(sE + pl * 64 + ((((slot >> 1) ^ (pl >> 2)) & 3) << 4) + ((slot & 1) << 3)) = pk;
+      }
+    }
+    {
+      const int pl0 = lane >> 2;                  // 16 rows per instruction, 4 lanes (chunks) per row
+      const int mrow = m0 + wm * 64 + pl0;
+      bf16_t* orow = p.out + ((long long)mrow * 64 + wn * 32 + (lane & 3) * 8);
+      const bool want_stats = p.stats != nullptr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pl = r * 16 + pl0;
+        const u32x4 o = *(const u32x4*)(sE + pl * 64 + ((((lane & 3) ^ (pl >> 2)) & 3) << 4));
+        if (mrow + r * 16 < p.M) {
+          *(u32x4*)(orow + r * (16 * 64)) = o;
+          if (want_stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 v = {bf16_lo(o[e]), bf16_hi(o[e])};
+              s1[e] += v;
+              s2[e] = __builtin_elementwise_fma(v, v, s2[e]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (p.stats != nullptr) {
+    // one partial row per workgroup; rows no workgroup owns are zero (the consumer sums ceil(M / 128) rows)
+    __syncthreads();
+    float* red = (float*)smem;               // [32 lane groups: wm*16 + lane>>2][2][64]
+    const int g = wm * 16 + (lane >> 2);
+    const int c0 = wn * 32 + (lane & 3) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[(g * 2 + 0) * 64 + c0 + 2 * e] = s1[e][0];
+      red[(g * 2 + 0) * 64 + c0 + 2 * e + 1] = s1[e][1];
+      red[(g * 2 + 1) * 64 + c0 + 2 * e] = s2[e][0];
+      red[(g * 2 + 1) * 64 + c0 + 2 * e + 1] = s2[e][1];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) s += red[(k * 2 + which) * 64 + c];
+      p.stats[((long long)blockIdx.x * 2 + which) * 64 + c] = s;
+      const int nrows = (p.M + 127) / 128;
+      for (int r = blockIdx.x + gridDim.x; r < nrows; r += gridDim.x) p.stats[((long long)r * 2 + which) * 64 + c] = 0.f;
+    }
+  }
+}
+
+int resident_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+    return cus;
+  }();
+  return n;
+}
+
+int launch_resident_c64(const Halo3x3Params& p, hipStream_t stream) {
+  const int ntiles = (p.M + 127) / 128;
+  const int slots = 2 * resident_cus();                // two workgroups per CU
+  const int grid = ntiles < slots ? ntiles : slots;
+  if (p.bias != nullptr || p.relu)
+    hipLaunchKernelGGL((conv3x3_c64_resident_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, p, ntiles);
+  else
+    hipLaunchKernelGGL((conv3x3_c64_resident_kernel<false>), dim3((unsigned)grid), dim3(256), 0, stream, p, ntiles);
+  return icamd_launch_status();
+}
+
 template <int BN, int WN, int MFR, int LA, int NB, int KS, int WPS>
 int launch_halo(const Halo3x3Params& p, hipStream_t stream) {
   constexpr int BM = (4 / WN) * MFR * 16;
@@ -322,14 +590,21 @@ int halo_mode() {
 
 }  // namespace
 
+// register-resident filter kernel: exactly 64 -> 64 channels, W a multiple of 8, tile + halo within 255 slots
+static bool resident_c64_ok(int W, int C, int Cout) {
+  static const int on = [] { const char* e = getenv("ICAMD_CONV3X3_RESIDENT"); return e ? atoi(e) : 1; }();
+  return on != 0 && C == 64 && Cout == 64 && W % 8 == 0 && 128 + 2 * W + 2 <= 255;
+}
+
 bool icamd_halo3x3_wanted(int N, int H, int W, int C, int Cout) {
   if (halo_mode() == 0) return false;
   // Default: the layers where it is faster than the implicit-GEMM kernel on MI355X at batch 256 (profiles/README.md,
   // round 2): >= 256 channels (256->256 at 14x14: 72 -> 63 us; 512->512 at 7x7: 85 -> 70 us).  At 64 / 128 channels the two
   // tie (the input tile is re-staged per 64-channel slice with nothing to overlap), so those stay on conv_igemm.hip.
   // ICAMD_CONV3X3_HALO=2 / 3 force the 128- / 256-pixel tiles for every eligible layer (tests).
-  if (halo_mode() == 1 && C < 256) return false;
   if (C % 64 != 0 || Cout % 8 != 0 || W < 3 || H < 3) return false;
+  if (resident_c64_ok(W, C, Cout)) return true;
+  if (halo_mode() == 1 && C < 256) return false;
   if ((long long)N * H * W >= (1ll << 30)) return false;
   if (2 * W + 3 + 128 > 4 * 12 * 8) return false;       // widest staged tile: 384 slots
   return true;
@@ -340,6 +615,7 @@ int icamd_halo3x3_launch(Halo3x3Params& p, hipStream_t stream) {
   p.M = p.N * p.H * p.W;
   p.divHW = make_fastdiv((unsigned)(p.H * p.W));
   p.divW = make_fastdiv((unsigned)p.W);
+  if (resident_c64_ok(p.W, p.C, p.Cout)) return launch_resident_c64(p, stream);
   const int bn = p.Cout <= 64 ? 64 : 128;
   p.ntiles_n = (p.Cout + bn - 1) / bn;
   // Pixel-tile height: 256, 224 or 128, whichever finishes the grid in the fewest (rounds x tile) at two workgroups per CU

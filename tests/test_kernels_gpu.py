@@ -291,6 +291,8 @@ def test_pointwise_gelu_epilogues(lib, case):
 HALO_CASES = [  # N, H, W, C, Cout: 3x3 stride 1 pad 1 layers routed to csrc/conv3x3_halo.hip
     (4, 14, 14, 256, 256), (2, 28, 28, 128, 128), (2, 56, 56, 64, 64), (6, 7, 7, 512, 512), (3, 9, 7, 64, 72),
     (2, 13, 11, 128, 256), (1, 3, 3, 64, 64), (5, 16, 16, 64, 128),
+    # 64 -> 64: the register-resident persistent kernel; > 256 tiles (workgroups loop, both LDS buffers), ragged last tile
+    (24, 56, 56, 64, 64), (40, 9, 13, 64, 64), (300, 16, 16, 64, 64),
 ]
 
 
@@ -346,7 +348,7 @@ def test_conv3x3_halo_every_tile_shape(mode):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, ICAMD_CONV3X3_HALO=mode)
+    env = dict(os.environ, ICAMD_CONV3X3_HALO=mode, ICAMD_CONV3X3_RESIDENT="0")   # 64 -> 64 on the streaming kernels too
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_conv3x3_halo_fwd_and_dgrad"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
