@@ -176,11 +176,12 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     h.N = d->N; h.H = d->IH; h.W = d->IW; h.C = d->Cin; h.Cout = d->Cout;
     return icamd_halo3x3_launch(h, (hipStream_t)stream);
   }
-  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && stats == nullptr &&
+  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
       icamd_gemm_nt_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.addend = (const bf16_t*)addend; g.bias = bias;
+    g.stats = stats;
     g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin; g.relu = relu; g.gelu_out = (bf16_t*)gelu_out; g.gelu_inplace = gelu_inplace;
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);
   }
@@ -241,11 +242,12 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
   if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
-  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && addend_bits == nullptr && f == nullptr &&
+  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && f == nullptr && !(addend_bits != nullptr && addend_sub2) &&
       icamd_gemm_nt_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {
     GemmNtParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.addend = (const bf16_t*)addend;
+    g.addend_bits = addend_bits;
     g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout; g.gelu_z = (const bf16_t*)gelu_z;
     if (addend_sub2) { g.sub2_h = d->IH; g.sub2_w = d->IW; }
     return icamd_gemm_nt_launch(g, (hipStream_t)stream);

@@ -339,21 +339,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_resident_kernel(const Halo
   unsigned char* const sE = smem + 2 * A_BYTES + wave * 4096;
   const unsigned lds_base = (unsigned)(uintptr_t)LPTR(smem);
 
-  // ---- this wave's filter half, once: fragment (k-step ks = tap*2 + half, channel fragment j): row wn*32 + j*16 + fr
-  bf16x8 wf[18][2];
-#pragma unroll
-  for (int ks = 0; ks < 18; ++ks) {
-    const int tap = ks >> 1;
-    const int wtap = p.flip ? 8 - tap : tap;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      wf[ks][j] = *(const bf16x8*)(p.wt + ((wn * 32 + j * 16 + fr) * 9 + wtap) * 64 + (ks & 1) * 32 + fq * 8);
-  }
-  // The filter must have ARRIVED before the tile loop: left to the compiler, its s_waitcnt vmcnt(0) would sit at the first
-  // use inside the loop, behind the next tile's LDS-DMA, and drain that every tile.  (The builtin, not inline asm: the
-  // compiler's wait-count bookkeeping sees it.)  simm16 = vmcnt 0, expcnt 7, lgkmcnt 15.
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-
   // Staging: instruction j of wave w covers slots (j*4 + w)*8 .. +7 (1 KiB of LDS); slot s holds pixel m0 - (W+1) + s with
   // its 16 B chunks rotated by s & 7 -- and s & 7 is lane >> 3 for every instruction, so a lane's source is one pointer
   // advanced by 32 pixels per instruction.
@@ -380,14 +365,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_resident_kernel(const Halo
     }
   };
 
+  int buf = 0;
+  int tile = blockIdx.x;
+  if (tile < ntiles) stage_a(tile * BM, smem);   // in flight under the filter loads below
+
+  // ---- this wave's filter half, once: fragment (k-step ks = tap*2 + half, channel fragment j): row wn*32 + j*16 + fr
+  bf16x8 wf[18][2];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) {
+    const int tap = ks >> 1;
+    const int wtap = p.flip ? 8 - tap : tap;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      wf[ks][j] = *(const bf16x8*)(p.wt + ((wn * 32 + j * 16 + fr) * 9 + wtap) * 64 + (ks & 1) * 32 + fq * 8);
+  }
+  // The filter must have ARRIVED before the tile loop: left to the compiler, its s_waitcnt vmcnt(0) would sit at the first
+  // use inside the loop, behind the next tile's LDS-DMA, and drain that every tile.  (The builtin, not inline asm: the
+  // compiler's wait-count bookkeeping sees it.)  simm16 = vmcnt 0, expcnt 7, lgkmcnt 15.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
 
-  int buf = 0;
-  int tile = blockIdx.x;
-  if (tile < ntiles) stage_a(tile * BM, smem);
-  halo_wait_vmcnt<0>();        // the first tile has no stores behind its loads: the counted wait below would let it through
+  // (the s_waitcnt above also covered the first tile's input, which has no stores behind its loads: the counted wait at the
+  // top of the loop would let it through)
   for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
     const int m0 = tile * BM;
     // this tile's input has landed for every wave, and every wave is done reading the other buffer (previous tile).

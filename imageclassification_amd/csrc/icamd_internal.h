@@ -61,7 +61,10 @@ struct GemmNtParams {
   const bf16_t* B;       // [N][K]
   bf16_t* out;           // [M][N]
   const bf16_t* addend;  // optional [M][N]
+  const unsigned char* addend_bits;   // optional, 1 bit per addend element (full-size addend only): counted where set
   const float* bias;     // optional [N]
+  float* stats;          // optional [ceil(M/128)][2][N]: per-channel sum / sum of squares of the rounded outputs, one row
+                         // per 256-row tile at row tile_m, zeros in the rows no tile owns
   int M, N, K;
   int sub2_h, sub2_w;    // > 0: rows are pixels of [.][sub2_h][sub2_w]; addend is [.][ceil(h/2)][ceil(w/2)][N], added at even (h, w)
   FastDiv divHW, divW;   // filled by the launcher when sub2_h > 0

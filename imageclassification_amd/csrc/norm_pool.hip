@@ -60,6 +60,13 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
   red[rl][0][cc] = s1;
   red[rl][1][cc] = s2;
   __syncthreads();
+  double t1 = 0.0, t2 = 0.0;
+  if (gridDim.y == 1) {
+    // a single chunk (<= 512 partial rows): no chunk row, no ticket -- the sums go straight to the finishing code
+    if (threadIdx.x >= 64 || c >= C) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { t1 += red[j][0][cc]; t2 += red[j][1][cc]; }
+  } else {
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6;
     double s = 0.0;
@@ -98,9 +105,9 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
   red[rl][1][cc] = p2;
   __syncthreads();
   if (threadIdx.x >= 64 || c >= C) return;
-  double t1 = 0.0, t2 = 0.0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) { t1 += red[j][0][cc]; t2 += red[j][1][cc]; }
+  }
   if constexpr (MODE == 0) {
     const double mean = t1 / a.count;
     double var = t2 / a.count - mean * mean;
@@ -694,6 +701,7 @@ inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } retu
 static void chunking(int nrows, int* rows_per_chunk, int* nchunks) {
   int rpc = 128;
   int nc = (nrows + rpc - 1) / rpc;
+  if (nrows <= 512) { rpc = nrows > 0 ? nrows : 1; nc = 1; }   // one workgroup per 64 channels, no ticket round
   if (nc > 64) { rpc = (nrows + 63) / 64; nc = (nrows + rpc - 1) / rpc; }
   *rows_per_chunk = rpc; *nchunks = nc;
 }

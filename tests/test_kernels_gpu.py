@@ -141,6 +141,7 @@ LARGE_POINTWISE = [
     (4, 64, 64, 256, 1024),     # exact tiles
     (1, 129, 127, 288, 1000),   # ragged M and N, K = 9 stages
     (2, 197, 64, 768, 2304),    # ViT qkv shape at a small batch
+    (8, 56, 56, 256, 256),      # Cin a multiple of 64: the mask-bit addend of the residual data gradient
 ]
 
 
@@ -166,6 +167,19 @@ def _run_large_pointwise(lib, cases):
             assert torch.isfinite(got).all()
             assert R.rel_l2(got, ref) <= 1e-3
             assert R.bf16_close(got, ref)
+        # BatchNorm statistics from the epilogue (training forward): the partial rows sum to the sums of the rounded outputs
+        rows = lib.icamd_conv2d_stats_rows(ctypes.byref(d))
+        stats = torch.full((rows, 2, Cout), float("nan"), device=DEV)
+        y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(xd), hip.ptr(wd), hip.ptr(y), None, None, hip.ptr(stats),
+                                    hip.stream_ptr()) == 0
+        sync()
+        got = y.float().cpu()
+        assert R.rel_l2(got, R.conv2d_fwd(x, w, 1, 0, None, None)) <= 1e-3
+        s1, s2 = R.conv2d_stats(got)
+        st = stats.double().cpu()
+        assert torch.isfinite(st).all()
+        assert torch.allclose(st.sum(0)[0], s1, rtol=1e-4, atol=1e-2) and torch.allclose(st.sum(0)[1], s2, rtol=1e-4, atol=1e-2)
         # data gradient of the same layer: dx[m][ci] = sum_co dy[m][co] w[co][ci] (+ addend)
         dy = rnd_bf16(N, H, W, Cout, seed=15)
         add_in = rnd_bf16(N, H, W, Cin, seed=16)
@@ -183,6 +197,17 @@ def _run_large_pointwise(lib, cases):
             assert torch.isfinite(got).all()
             assert R.rel_l2(got, ref) <= 1e-3
             assert R.bf16_close(got, ref)
+        if Cin % 64 == 0:   # addend counted only where its ReLU-mask bit is set (residual shortcut)
+            mask = torch.rand(N, H, W, Cin, generator=torch.Generator().manual_seed(17)) > 0.4
+            bits = (mask.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
+            ref = R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in * mask)
+            dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ad, bd = to_dev_bf16(add_in), bits.to(DEV)
+            assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), hip.ptr(bd),
+                                          hip.stream_ptr()) == 0
+            sync()
+            got = dx.float().cpu()
+            assert torch.isfinite(got).all() and R.rel_l2(got, ref) <= 1e-3 and R.bf16_close(got, ref)
 
 
 def test_pointwise_large_tile_gemm(lib):
