@@ -18,6 +18,7 @@
 // taps negated; stride-2 gradients run as 4 parity classes (ostr=2, only the taps that hit each class).
 #include "common.h"
 #include "icamd_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,6 +30,8 @@ constexpr int BK = 64;
 #endif
 
 // EPI 0: out = [relu](acc (+bias)(+addend)); optional statistics of the rounded outputs (BatchNorm forward).
+// EPI 2: EPI 0 with every optional operand compiled OUT (no bias, addend, ReLU, GELU; statistics still optional): the plain
+//        training forward and the plain data gradient, i.e. most launches of a ResNet step, run ~1/10 of the epilogue code.
 // EPI 1: data-gradient with the next BatchNorm-backward fused in: g = (acc + addend) * [ReLU mask], out = g, and the
 //        partial rows hold sum(g) and sum(g * xhat), xhat from the BN input `bnb_y` (BatchNorm backward, pass 1).
 // KMODE 3: the ResNet stem (7x7 stride 2 pad 3 on the [N][H][W+8][4] layout of icamd_pack_input_rgb4): the reduction is
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
 
   // (1) MFMA-layout adds + rounding + LDS write
   {
-    const bool has_addend = p.addend != nullptr;   // wave-uniform
+    const bool has_addend = EPI != 2 && p.addend != nullptr;   // wave-uniform
     int moff[4];
     unsigned long long abw[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 #pragma unroll
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
       const int cg = n0 + cl;
       const int cgc = cg < p.Cout ? cg : 0;                 // clamped: loads stay in bounds, values unused
       f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
+      if (EPI != 2 && p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
       u32x2 av[4];
       unsigned int ab[4] = {0xffu, 0xffu, 0xffu, 0xffu};
       if (has_addend) {
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
           v[2] += (ab[i] & 4u) ? bf16_lo(a[1]) : 0.f;
           v[3] += (ab[i] & 8u) ? bf16_hi(a[1]) : 0.f;
         }
-        if (p.relu) {   // inference epilogue (BatchNorm folded into filters + bias): NaN passes through like torch.relu
+        if (EPI != 2 && p.relu) {   // inference epilogue (BatchNorm folded into filters + bias): NaN passes through like torch.relu
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
         }
@@ -388,10 +391,14 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
           s2[e] += gg[e] * ((yy[e] - bmu[e]) * bis[e]);
         }
       } else {
-        if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + roff[ps]));
-        if (p.gelu_inplace) o = gelu8(o);
+        if constexpr (EPI != 2) {
+          if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + roff[ps]));
+          if (p.gelu_inplace) o = gelu8(o);
+        }
         *(u32x4*)(p.out + roff[ps]) = o;
-        if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + roff[ps]) = gelu8(o);
+        if constexpr (EPI != 2) {
+          if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + roff[ps]) = gelu8(o);
+        }
         if (p.stats != nullptr) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -466,6 +473,10 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
     return bn == 64 ? launch<64, 3, 0>(p, stream) : launch<128, 3, 0>(p, stream);
   }
   const bool tail = !cin8 && (p.Cin % 64 != 0);   // single tap, channel count not a multiple of the k-step
+  const bool plain = p.bias == nullptr && p.addend == nullptr && !p.relu && p.gelu_out == nullptr && !p.gelu_inplace &&
+                     p.gelu_z == nullptr;
+  static const bool lean_on = [] { const char* e = getenv("ICAMD_IGEMM_LEAN"); return !(e && atoi(e) == 0); }();
+  if (lean_on && plain && !cin8 && !tail) return bn == 64 ? launch<64, 0, 2>(p, stream) : launch<128, 0, 2>(p, stream);
   if (bn == 64) return cin8 ? launch<64, 1, 0>(p, stream) : (tail ? launch<64, 2, 0>(p, stream) : launch<64, 0, 0>(p, stream));
   return cin8 ? launch<128, 1, 0>(p, stream) : (tail ? launch<128, 2, 0>(p, stream) : launch<128, 0, 0>(p, stream));
 }
