@@ -353,6 +353,11 @@ size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
   if (M >= (1ll << 30)) return 0;
   const int Ktot = d->KH * d->KW * d->Cin;
   icamd_wgrad_plan((int)M, d->Cout, Ktot, &S, &rows);
+  if (icamd_wgrad_halo_wanted(d->KH, d->KW, d->stride, d->pad, d->OH, d->OW, d->Cin, d->Cout, M)) {
+    int S2 = 1;   // the halo kernel has its own split; the bias-gradient form of the same layer stays on the general one
+    icamd_wgrad_halo_plan((int)M, d->Cin, d->Cout, &S2, &rows);
+    if (S2 > S) S = S2;
+  }
   return (size_t)S * d->Cout * ((size_t)Ktot + 1) * sizeof(float);   // filter slabs + one bias row per split
 }
 
@@ -383,9 +388,15 @@ static int wgrad_impl(const icamd_conv_desc* d, const void* x, const void* dy, f
   p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.M = d->N * d->OH * d->OW; p.Ktot = d->KH * d->KW * d->Cin;
-  icamd_wgrad_plan(p.M, p.Cout, p.Ktot, &p.S, &p.rows_per_split);
-  if (dbias != nullptr) p.bias_slab = p.slab + (size_t)p.S * p.Cout * p.Ktot;
-  int rc = icamd_wgrad_launch(p, (hipStream_t)stream);
+  int rc;
+  if (dbias == nullptr && icamd_wgrad_halo_wanted(d->KH, d->KW, d->stride, d->pad, d->OH, d->OW, d->Cin, d->Cout, p.M)) {
+    icamd_wgrad_halo_plan(p.M, p.Cin, p.Cout, &p.S, &p.rows_per_split);
+    rc = icamd_wgrad_halo_launch(p, (hipStream_t)stream);
+  } else {
+    icamd_wgrad_plan(p.M, p.Cout, p.Ktot, &p.S, &p.rows_per_split);
+    if (dbias != nullptr) p.bias_slab = p.slab + (size_t)p.S * p.Cout * p.Ktot;
+    rc = icamd_wgrad_launch(p, (hipStream_t)stream);
+  }
   if (rc) return rc;
   rc = icamd_slab_reduce_launch(p.slab, dw, (long long)p.Cout * p.Ktot, p.S, accumulate, (hipStream_t)stream);
   if (rc || dbias == nullptr) return rc;

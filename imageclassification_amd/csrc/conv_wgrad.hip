@@ -513,6 +513,197 @@ int pick_side(int n) {
   return ((n + 255) / 256 * 256 - n) * 4 <= n ? 256 : 128;     // at most 25 % padding for the 256 side
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 weight gradient with the input staged ONCE per pixel chunk ("halo" form of conv3x3_halo.hip):
+//   dw[co][tap][ci] = sum_px dy[px][co] * x[px + (dh-1)*W + (dw-1)][ci] * [tap inside the image]
+// The implicit-GEMM kernels above re-gather x once per tap (9x through L2; PMC: TCC busy 74-91 %).  Here a workgroup owns
+// one 64 (co) x 64 (ci) block of the filter for ALL NINE taps -- 9 x 64 x 64 fp32 accumulators = 72 VGPRs in each of its
+// eight waves (wave = 32-channel half of co x 16-channel quarter of ci) -- and a range of pixels, walked in chunks of 128:
+//   * per chunk, LDS-DMA stages the raster range [chunk - W - 1, chunk + 128 + W + 1) of x (64 channels, 128 B rows) and
+//     the chunk's 128 rows of dy, double-buffered; both operands are read with ds_read_b64_tr_b16 (the reduction index,
+//     the pixel, is the slow memory dimension of both), 32 B blocks XOR-swizzled by a key of (row mod 16) so the reads
+//     are conflict-free at any tap offset -- and constant over all steps, since a step advances 32 rows;
+//   * a tap is an offset dh*W + dw on the row of the x read: 18 per-lane byte offsets computed once per KERNEL; pixels
+//     whose tap leaves the image read a row of zeros instead (one v_cndmask per read);
+//   * per 32-pixel step and wave: 22 transposed reads, 18 MFMAs (v_mfma_f32_16x16x32_bf16).
+// The ResNet-50 3x3 layers at batch 256 all become 256 workgroups x 3136 pixels (1 / 4 / 16 / 64 filter blocks x
+// 256 / 64 / 16 / 4 pixel splits), 37.7 MB of fp32 slabs, reduced in fixed order by slab_reduce_kernel.
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_read_pair_off(unsigned a0, unsigned a1) {
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+constexpr int HW_CH = 128;                 // pixels per chunk
+constexpr int HW_XS = 256;                 // staged x rows per buffer: HW_CH + 2W + 2 <= 256
+constexpr int HW_XB = HW_XS * 128, HW_YB = HW_CH * 128;
+
+// LDS map: [dy buffer 0 | dy buffer 1 | x buffer 0 | x buffer 1 | 128 B of zeros].  A read's buffer and step are an IMMEDIATE
+// offset (buffer * size + step * 32 rows; x: <= 45056, dy: <= 28672, inside the 16-bit field), so the 18 + 4 per-lane read
+// addresses are constants of the whole kernel and cost no VALU work inside the loop.
+constexpr int HW_XBASE = 2 * HW_YB;
+constexpr int HW_ZERO = 2 * HW_YB + 2 * HW_XB;
+
+struct HaloLane {
+  unsigned xa[9][2];   // x read addresses (tap, row select), buffer 0, step 0
+  unsigned ya[2][2];   // dy read addresses (channel fragment, row select), buffer 0, step 0
+  unsigned zaddr;      // the zero row
+};
+
+template <int N>
+__device__ __forceinline__ void halo_wait_tap(bf16x8& xf, bf16x8& y0, bf16x8& y1) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(xf), "+v"(y0), "+v"(y1) : "n"(N) : "memory");
+}
+
+template <int BUF, int ST>
+__device__ __forceinline__ void halo_wgrad_step(const WgradParams& p, const HaloLane& h, int px0, f32x4 (&acc)[9][2]) {
+  // tap validity of this lane's two pixel rows (px0 + 32*ST and + 4)
+  bool hv0[2], hv2[2], wv0[2], wv2[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    unsigned int m = (unsigned)(px0 + ST * 32 + s * 4);
+    if (m >= (unsigned)p.M) m = 0;           // rows past M carry dy = 0; any in-range pixel will do
+    const unsigned int n = fdiv(m, p.divHW);
+    const unsigned int rem = m - n * (p.OH * p.OW);
+    const int hh = (int)fdiv(rem, p.divW);
+    const int ww = (int)(rem - (unsigned)hh * p.OW);
+    hv0[s] = hh > 0; hv2[s] = hh + 1 < p.OH; wv0[s] = ww > 0; wv2[s] = ww + 1 < p.OW;
+  }
+  constexpr int XOFF = BUF * HW_XB + ST * 32 * 128;
+  constexpr int YOFF = BUF * HW_YB + ST * 32 * 128;
+  const unsigned zsel = h.zaddr - (unsigned)XOFF;
+  bf16x8 yf[2], xf[9];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) yf[j] = tr_read_pair_off<YOFF>(h.ya[j][0], h.ya[j][1]);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dh = t / 3, dw = t % 3;
+    unsigned a[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bool okh = dh == 0 ? hv0[s] : (dh == 2 ? hv2[s] : true);
+      const bool okw = dw == 0 ? wv0[s] : (dw == 2 ? wv2[s] : true);
+      a[s] = (okh && okw) ? h.xa[t][s] : zsel;
+    }
+    xf[t] = tr_read_pair_off<XOFF>(a[0], a[1]);
+  }
+  // Progressive waits: the reads return in issue order (4 for dy, then 2 per tap), so tap t may start once at most
+  // 2 * (8 - t) reads are outstanding -- the MFMAs of the first taps run under the LDS latency of the last ones.  Each wait
+  // names the fragment it releases as an in/out operand, which pins that tap's MFMAs below it.
+  __builtin_amdgcn_sched_barrier(0);
+  halo_wait_tap<15>(xf[0], yf[0], yf[1]);   // lgkmcnt is a 4-bit field: 15 (not 16) outstanding is the weakest first wait
+#pragma unroll
+  for (int j = 0; j < 2; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0], yf[j], acc[0][j], 0, 0, 0);
+#define ICAMD_HALO_TAP(T)                                                                                        \
+  halo_wait_tap<2 * (8 - T)>(xf[T], yf[0], yf[1]);                                                               \
+  acc[T][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[T], yf[0], acc[T][0], 0, 0, 0);                         \
+  acc[T][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[T], yf[1], acc[T][1], 0, 0, 0);
+  ICAMD_HALO_TAP(1) ICAMD_HALO_TAP(2) ICAMD_HALO_TAP(3) ICAMD_HALO_TAP(4)
+  ICAMD_HALO_TAP(5) ICAMD_HALO_TAP(6) ICAMD_HALO_TAP(7) ICAMD_HALO_TAP(8)
+#undef ICAMD_HALO_TAP
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_halo_kernel(const WgradParams p, const int nblk_ci, const int nblk) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HW_ZERO + 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int coh = wave & 1, cif = wave >> 1;
+  const int split = blockIdx.x / nblk, blk = blockIdx.x - split * nblk;
+  const int cob = blk / nblk_ci, cib = blk - cob * nblk_ci;
+  const int W = p.OW;
+  const int p_begin = split * p.rows_per_split;
+  const int p_end = (p.M < p_begin + p.rows_per_split) ? p.M : p_begin + p.rows_per_split;
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+  const unsigned lds_base = (unsigned)(uintptr_t)LPTR(smem);
+  if (tid < 8) *(u32x4*)(smem + HW_ZERO + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+
+  // ---- staging roles.  An LDS-DMA instruction writes 8 rows of 128 B; instruction j of wave w covers rows (j*8 + w)*8..+7.
+  // Row r keeps its 32 B blocks at block ^ key(r), key(r) = ((r>>1)&1) | (((r>>3)&1)<<1): r mod 16 = (w&1)*8 + lane>>3.
+  const int st_row = wave * 8 + (lane >> 3);                    // + j*64
+  const int st_key = (((lane >> 3) >> 1) & 1) | ((wave & 1) << 1);
+  const int st_chunk = ((((lane & 7) >> 1) ^ st_key) << 1) | (lane & 1);   // 16 B source chunk of this lane's LDS position
+  auto stage = [&](int cpx, int buf) {
+    unsigned char* xb = smem + HW_XBASE + buf * HW_XB;
+    unsigned char* yb = smem + buf * HW_YB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {        // x: 256 rows = pixels cpx - W - 1 ...
+      const int pix = cpx - (W + 1) + j * 64 + st_row;
+      const bf16_t* src = (pix >= 0 && pix < p.M) ? p.x + ((long long)pix * p.Cin + cib * 64 + st_chunk * 8) : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(xb + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {        // dy: the chunk's 128 rows; rows past the split's end are zeros
+      const int pix = cpx + j * 64 + st_row;
+      const bf16_t* src = pix < p_end ? p.dy + ((long long)pix * p.Cout + cob * 64 + st_chunk * 8) : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(yb + (j * 8 + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- read roles (ds_read_b64_tr_b16: lane -> row 8g + q (+4), 8 B at 8*pq inside a 32 B channel block)
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const int r0 = 8 * g + q;
+  HaloLane h;
+  h.zaddr = lds_base + (unsigned)HW_ZERO;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = r0 + 4 * s + (t / 3) * W + (t % 3);       // staged row of pixel (chunk + r) + (dh-1)*W + (dw-1)
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      h.xa[t][s] = lds_base + (unsigned)(HW_XBASE + row * 128 + ((cif ^ key) << 5) + 8 * pq);
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = r0 + 4 * s;
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      h.ya[j][s] = lds_base + (unsigned)(row * 128 + (((coh * 2 + j) ^ key) << 5) + 8 * pq);
+    }
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (p_begin < p_end) stage(p_begin, 0);
+  for (int cpx = p_begin; cpx < p_end; cpx += 2 * HW_CH) {
+    // ---- even chunk: buffers 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // this chunk landed for every wave; the other buffers are free again
+    if (cpx + HW_CH < p_end) stage(cpx + HW_CH, 1);
+    halo_wgrad_step<0, 0>(p, h, cpx + r0, acc);
+    halo_wgrad_step<0, 1>(p, h, cpx + r0, acc);
+    halo_wgrad_step<0, 2>(p, h, cpx + r0, acc);
+    halo_wgrad_step<0, 3>(p, h, cpx + r0, acc);
+    if (cpx + HW_CH >= p_end) break;
+    // ---- odd chunk: buffers 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (cpx + 2 * HW_CH < p_end) stage(cpx + 2 * HW_CH, 0);
+    halo_wgrad_step<1, 0>(p, h, cpx + HW_CH + r0, acc);
+    halo_wgrad_step<1, 1>(p, h, cpx + HW_CH + r0, acc);
+    halo_wgrad_step<1, 2>(p, h, cpx + HW_CH + r0, acc);
+    halo_wgrad_step<1, 3>(p, h, cpx + HW_CH + r0, acc);
+  }
+
+  // acc[t][j]: rows = input channels 4*(lane>>4) .. +3 of this wave's 16, column = output channel lane & 15
+  float* slab = p.slab + (long long)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = cob * 64 + coh * 32 + j * 16 + (lane & 15);
+      const int kk = t * p.Cin + cib * 64 + cif * 16 + 4 * (lane >> 4);
+      *(f32x4*)(slab + (long long)co * p.Ktot + kk) = acc[t][j];
+    }
+}
+
 template <int BMK, int BNC, int WK, int WC, int NSLOT, int WPS>
 int launch_ring(const WgradParams& p, hipStream_t stream) {
   dim3 grid((unsigned)(p.ntiles_k * p.ntiles_c * p.S));
@@ -594,6 +785,41 @@ void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split) {
   rows = (rows + gran - 1) / gran * gran;
   *rows_per_split = rows;
   *S = (M + rows - 1) / rows;
+}
+
+static int halo_wgrad_mode() {
+  static const int m = [] { const char* e = getenv("ICAMD_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+  return m;
+}
+
+// 3x3 / stride 1 / pad 1 with both channel counts multiples of 64 and a staged row range within 256 rows
+bool icamd_wgrad_halo_wanted(int KH, int KW, int stride, int pad, int H, int W, int Cin, int Cout, long long M) {
+  if (halo_wgrad_mode() == 0) return false;
+  return KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && H >= 2 && W >= 2 &&
+         HW_CH + 2 * W + 2 <= HW_XS && M < (1ll << 30);
+}
+
+// pixel split of the halo kernel: (filter blocks) x S workgroups ~ one per CU, whole chunks per split
+void icamd_wgrad_halo_plan(int M, int Cin, int Cout, int* S, int* rows_per_split) {
+  const int nblk = (Cin / 64) * (Cout / 64);
+  int s = (256 + nblk - 1) / nblk;
+  const int cap = (M + HW_CH - 1) / HW_CH;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  int rows = (M + s - 1) / s;
+  rows = (rows + HW_CH - 1) / HW_CH * HW_CH;
+  *rows_per_split = rows;
+  *S = (M + rows - 1) / rows;
+}
+
+int icamd_wgrad_halo_launch(WgradParams& p, hipStream_t stream) {
+  if (!icamd_wgrad_halo_wanted(p.KH, p.KW, p.stride, p.pad, p.OH, p.OW, p.Cin, p.Cout, p.M) || p.bias_slab != nullptr)
+    return ICAMD_ERR_UNSUPPORTED;
+  p.divHW = make_fastdiv((unsigned)(p.OH * p.OW));
+  p.divW = make_fastdiv((unsigned)p.OW);
+  const int nci = p.Cin / 64, nblk = nci * (p.Cout / 64);
+  hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3((unsigned)(nblk * p.S)), dim3(512), 0, stream, p, nci, nblk);
+  return icamd_launch_status();
 }
 
 int icamd_wgrad_launch(WgradParams& p, hipStream_t stream) {

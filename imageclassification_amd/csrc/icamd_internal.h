@@ -95,7 +95,11 @@ struct WgradParams {
 };
 int icamd_wgrad_launch(WgradParams& p, hipStream_t stream);
 void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split);
-void icamd_wgrad_tile(long long M, int Ktot, int Cout, int* bmk, int* bnc);   // output-tile sides the launcher will use
+void icamd_wgrad_tile(long long M, int Ktot, int Cout, int* bmk, int* bnc);
+// halo-staged 3x3 / stride 1 weight gradient (conv_wgrad.hip): own pixel split; slab layout as the other kernels
+bool icamd_wgrad_halo_wanted(int KH, int KW, int stride, int pad, int H, int W, int Cin, int Cout, long long M);
+void icamd_wgrad_halo_plan(int M, int Cin, int Cout, int* S, int* rows_per_split);
+int icamd_wgrad_halo_launch(WgradParams& p, hipStream_t stream);   // output-tile sides the launcher will use
 // out[i] = (accumulate ? out[i] : 0) + sum over S slabs of slab[s][i], fixed order; n % 4 == 0
 int icamd_slab_reduce_launch(const float* slab, float* out, long long n, int S, int accumulate, hipStream_t stream,
                              int stem7_mask = 0);

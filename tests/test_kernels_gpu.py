@@ -381,7 +381,11 @@ def test_conv3x3_halo_every_tile_shape(mode):
 
 WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0),
                             (4, 14, 14, 256, 256, 3, 1, 1),      # 256x256 ring tile: 9 filter tiles, ragged last stage
-                            (3, 9, 9, 512, 256, 1, 1, 0), (2, 14, 14, 256, 512, 3, 2, 1)]
+                            (3, 9, 9, 512, 256, 1, 1, 0), (2, 14, 14, 256, 512, 3, 2, 1),
+                            # 3x3 / stride 1 with channel counts multiples of 64: the halo-staged kernel (image borders, chunks
+                            # that straddle rows and images, ragged last chunk, several chunks per split, tiny images)
+                            (2, 9, 7, 64, 128, 3, 1, 1), (3, 7, 7, 128, 64, 3, 1, 1), (5, 10, 13, 64, 64, 3, 1, 1),
+                            (1, 2, 2, 64, 64, 3, 1, 1), (24, 28, 28, 64, 64, 3, 1, 1), (300, 7, 7, 128, 128, 3, 1, 1)]
 
 
 def test_conv_wgrad_every_ring_tile_shape():
@@ -391,7 +395,7 @@ def test_conv_wgrad_every_ring_tile_shape():
     import os
     import subprocess
     import sys
-    env = dict(os.environ, ICAMD_WGRAD_RING="2")
+    env = dict(os.environ, ICAMD_WGRAD_RING="2", ICAMD_WGRAD_HALO="0")   # 3x3 cases through the ring shapes as well
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
                         "test_conv_wgrad and not every_ring"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
