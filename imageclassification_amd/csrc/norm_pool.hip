@@ -454,79 +454,130 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(const bf16_t* __
 // BNRELU: x is a raw conv output; every window element is first mapped to bf16(relu(x*scale[c] + shift[c])) -- exactly the
 // tensor icamd_bn_apply would have stored -- so BatchNorm-apply + ReLU + max-pool of the ResNet stem is one pass that
 // reads the conv output once and never writes the full-resolution activation.
+// Index arithmetic is 32-bit with precomputed reciprocals (the launcher refuses >= 2^31 vectors): 64-bit `%` and `/` cost
+// more VALU work per output than the nine window loads.  The grid's thread count is a multiple of C/8, so a thread's
+// 8-channel group -- and its BatchNorm scale / shift -- never change.
+struct PoolDivs { FastDiv cpr, ow, oh; };
+
 template <bool BNRELU>
 __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                                unsigned char* __restrict__ idx, int N, int IH, int IW,
                                                                int C, int OH, int OW, const float* __restrict__ scale,
-                                                               const float* __restrict__ shift) {
-  const int cpr = C >> 3;
-  const long long total = (long long)N * OH * OW * cpr;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cg = (int)(i % cpr);
-    long long t = i / cpr;
-    const int ow = (int)(t % OW); t /= OW;
-    const int oh = (int)(t % OH);
-    const int n = (int)(t / OH);
-    float best[8];
-    int bi[8];
+                                                               const float* __restrict__ shift, const PoolDivs dv) {
+  const unsigned int cpr = (unsigned)C >> 3;
+  const unsigned int total = (unsigned)N * OH * OW * cpr;
+  const unsigned int stride = gridDim.x * blockDim.x;
+  unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int cg = i - fdiv(i, dv.cpr) * cpr;
+  float sc[8], sh[8];
+  if constexpr (BNRELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
-    bool first = true;
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[cg * 8 + e]; sh[e] = shift[cg * 8 + e]; }
+  }
+  for (; i < total; i += stride) {
+    unsigned int t = fdiv(i, dv.cpr);
+    const unsigned int t1 = fdiv(t, dv.ow);
+    const int ow = (int)(t - t1 * OW);
+    const unsigned int n = fdiv(t1, dv.oh);
+    const int oh = (int)(t1 - n * OH);
+    if constexpr (BNRELU) {
+      // The window elements are bf16(relu(.)) >= 0 (or NaN): their bit patterns order like the values, NaN above all, so
+      // key = bits << 8 | (15 - position) makes ONE v_max_u32 pick the largest value, the FIRST position among equals,
+      // and a NaN if there is one (torch.max_pool2d propagates NaN; with several NaNs in a window it records the last,
+      // this the first -- a NaN step is skipped by the engine either way).
+      unsigned int key[8];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ih = oh * 2 - 1 + r;
-      if ((unsigned)ih >= (unsigned)IH) continue;
+      for (int e = 0; e < 8; ++e) key[e] = 0u;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int iw = ow * 2 - 1 + s;
-        if ((unsigned)iw >= (unsigned)IW) continue;
-        const u32x4 v = ((const u32x4*)x)[((long long)(n * IH + ih) * IW + iw) * cpr + cg];
-        float f[8];
+      for (int r = 0; r < 3; ++r) {
+        const int ih = oh * 2 - 1 + r;
+        if ((unsigned)ih >= (unsigned)IH) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(v[e]); f[2 * e + 1] = bf16_hi(v[e]); }
-        if constexpr (BNRELU) {
+        for (int s = 0; s < 3; ++s) {
+          const int iw = ow * 2 - 1 + s;
+          if ((unsigned)iw >= (unsigned)IW) continue;
+          const u32x4 v = ((const u32x4*)x)[((n * IH + ih) * IW + iw) * cpr + cg];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float a = fmaf(f[e], scale[cg * 8 + e], shift[cg * 8 + e]);
-            a = a < 0.f ? 0.f : a;
-            f[e] = bf16_to_f32(f32_to_bf16(a));
+          for (int e = 0; e < 4; ++e) {
+            float a0 = fmaf(bf16_lo(v[e]), sc[2 * e], sh[2 * e]);
+            float a1 = fmaf(bf16_hi(v[e]), sc[2 * e + 1], sh[2 * e + 1]);
+            a0 = a0 < 0.f ? 0.f : a0;
+            a1 = a1 < 0.f ? 0.f : a1;
+            const unsigned int pk = pack_bf16x2(a0, a1) & 0x7fff7fffu;   // -0.0 (a < 0 is false for it) orders as +0.0
+            const unsigned int k0 = ((pk & 0xffffu) << 8) | (unsigned)(15 - (r * 3 + s));
+            const unsigned int k1 = ((pk >> 16) << 8) | (unsigned)(15 - (r * 3 + s));
+            key[2 * e] = key[2 * e] > k0 ? key[2 * e] : k0;
+            key[2 * e + 1] = key[2 * e + 1] > k1 ? key[2 * e + 1] : k1;
           }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (first || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = r * 3 + s; }
-        }
-        first = false;
       }
-    }
-    u32x4 o;
+      // (key 0 can only remain if the window is empty, which a 3x3/s2/p1 window over IH, IW >= 1 never is)
+      u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(best[2 * e], best[2 * e + 1]);
-    ((u32x4*)out)[i] = o;
-    if (idx != nullptr) {
-      u32x2 iv;
-      iv[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-      iv[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
-      ((u32x2*)idx)[i] = iv;
+      for (int e = 0; e < 4; ++e) o[e] = ((key[2 * e] >> 8) & 0xffffu) | ((key[2 * e + 1] >> 8) << 16);
+      ((u32x4*)out)[i] = o;
+      if (idx != nullptr) {
+        u32x2 iv;
+        iv[0] = (15u - (key[0] & 15u)) | ((15u - (key[1] & 15u)) << 8) | ((15u - (key[2] & 15u)) << 16) | ((15u - (key[3] & 15u)) << 24);
+        iv[1] = (15u - (key[4] & 15u)) | ((15u - (key[5] & 15u)) << 8) | ((15u - (key[6] & 15u)) << 16) | ((15u - (key[7] & 15u)) << 24);
+        ((u32x2*)idx)[i] = iv;
+      }
+    } else {
+      float best[8];
+      int bi[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+      bool first = true;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int ih = oh * 2 - 1 + r;
+        if ((unsigned)ih >= (unsigned)IH) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int iw = ow * 2 - 1 + s;
+          if ((unsigned)iw >= (unsigned)IW) continue;
+          const u32x4 v = ((const u32x4*)x)[((n * IH + ih) * IW + iw) * cpr + cg];
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { f[2 * e] = bf16_lo(v[e]); f[2 * e + 1] = bf16_hi(v[e]); }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (first || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = r * 3 + s; }
+          }
+          first = false;
+        }
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(best[2 * e], best[2 * e + 1]);
+      ((u32x4*)out)[i] = o;
+      if (idx != nullptr) {
+        u32x2 iv;
+        iv[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        iv[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        ((u32x2*)idx)[i] = iv;
+      }
     }
   }
 }
 
-// dx[n,h,w,c] = sum over the (<=4) windows that cover (h,w) and whose recorded argmax is (h,w)
+// dx[n,h,w,c] = sum over the (<=4) windows that cover (h,w) and whose recorded argmax is (h,w).  dv: reciprocals of
+// C/8, IW, IH.
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ dout,
                                                                const unsigned char* __restrict__ idx,
                                                                bf16_t* __restrict__ dx, int N, int IH, int IW, int C,
-                                                               int OH, int OW) {
-  const int cpr = C >> 3;
-  const long long total = (long long)N * IH * IW * cpr;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cg = (int)(i % cpr);
-    long long t = i / cpr;
-    const int w = (int)(t % IW); t /= IW;
-    const int h = (int)(t % IH);
-    const int n = (int)(t / IH);
+                                                               int OH, int OW, const PoolDivs dv) {
+  const unsigned int cpr = (unsigned)C >> 3;
+  const unsigned int total = (unsigned)N * IH * IW * cpr;
+  const unsigned int stride = gridDim.x * blockDim.x;
+  unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned int cg = i - fdiv(i, dv.cpr) * cpr;
+  for (; i < total; i += stride) {
+    const unsigned int t = fdiv(i, dv.cpr);
+    const unsigned int t1 = fdiv(t, dv.ow);
+    const int w = (int)(t - t1 * IW);
+    const unsigned int n = fdiv(t1, dv.oh);
+    const int h = (int)(t1 - n * IH);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -538,15 +589,17 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __r
       for (int ow = ow_lo; ow <= ow_hi; ++ow) {
         if (ow >= OW) continue;
         const int s = w - (ow * 2 - 1);
-        const int code = r * 3 + s;
-        const long long o = ((long long)(n * OH + oh) * OW + ow) * cpr + cg;
+        const unsigned int code4 = (unsigned)(r * 3 + s) * 0x01010101u;
+        const unsigned int o = ((n * OH + oh) * OW + ow) * cpr + cg;
         const u32x2 iv = ((const u32x2*)idx)[o];
         const u32x4 d = ((const u32x4*)dout)[o];
+        // a byte of iv ^ code4 is zero where that channel's argmax is this pixel
+        const unsigned int m0 = iv[0] ^ code4, m1 = iv[1] ^ code4;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int code_e = (iv[e >> 2] >> ((e & 3) * 8)) & 0xff;
-          const float dv = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
-          if (code_e == code) acc[e] += dv;
+          const unsigned int mb = ((e < 4 ? m0 : m1) >> ((e & 3) * 8)) & 0xffu;
+          const float dvv = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
+          acc[e] += mb == 0u ? dvv : 0.f;
         }
       }
     }
@@ -852,30 +905,36 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
   return icamd_launch_status();
 }
 
+static PoolDivs pool_divs(int C, int W, int H) {
+  PoolDivs d;
+  d.cpr = make_fastdiv((unsigned)(C / 8)); d.ow = make_fastdiv((unsigned)W); d.oh = make_fastdiv((unsigned)H);
+  return d;
+}
+
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s) {
-  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  if (C % 8 != 0 || (long long)N * IH * IW * (C / 8) >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
   const long long total = (long long)N * OH * OW * (C / 8);
-  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<false>, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, x, out, idx, N, IH, IW,
-                     C, OH, OW, nullptr, nullptr);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<false>, dim3(elementwise_grid(total, C / 8) * 4), dim3(256), 0, s, x, out, idx, N,
+                     IH, IW, C, OH, OW, nullptr, nullptr, pool_divs(C, OW, OH));
   return icamd_launch_status();
 }
 
 int icamd_bn_relu_maxpool_fwd_launch(const bf16_t* y, const float* scale, const float* shift, bf16_t* out, unsigned char* idx,
                                      int N, int IH, int IW, int C, int OH, int OW, hipStream_t s) {
-  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  if (C % 8 != 0 || (long long)N * IH * IW * (C / 8) >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
   const long long total = (long long)N * OH * OW * (C / 8);
-  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<true>, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, y, out, idx, N, IH, IW,
-                     C, OH, OW, scale, shift);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<true>, dim3(elementwise_grid(total, C / 8) * 4), dim3(256), 0, s, y, out, idx, N,
+                     IH, IW, C, OH, OW, scale, shift, pool_divs(C, OW, OH));
   return icamd_launch_status();
 }
 
 int icamd_maxpool_bwd_launch(const bf16_t* dout, const unsigned char* idx, bf16_t* dx, int N, int IH, int IW, int C, int OH,
                              int OW, hipStream_t s) {
-  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  if (C % 8 != 0 || (long long)N * IH * IW * (C / 8) >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
   const long long total = (long long)N * IH * IW * (C / 8);
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for(total, 256, 1) * 4), dim3(256), 0, s, dout, idx, dx, N, IH, IW,
-                     C, OH, OW);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(elementwise_grid(total, C / 8) * 4), dim3(256), 0, s, dout, idx, dx, N, IH,
+                     IW, C, OH, OW, pool_divs(C, IW, IH));
   return icamd_launch_status();
 }
 

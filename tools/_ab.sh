@@ -1,15 +1,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "wgrad" 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp
-for shape in "64 64 3 1 56" "256 256 3 1 14"; do
-rm -rf $R/gpurun_out/gl
-timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/gl -- python3 $R/tools/one_layer.py $shape 10 wgrad > /dev/null 2>&1
-python3 - <<PY
-import csv,glob
-f=glob.glob("$R/gpurun_out/gl/**/*kernel_stats.csv", recursive=True)[0]
-for r in csv.DictReader(open(f)):
-    if 'wgrad' in r['Name'] or 'slab' in r['Name']: print("$shape", r['Name'][27:75], r['Calls'], round(float(r['AverageNs'])/1e3,1))
-PY
-done
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "pool" 2>&1 | tail -3
+timeout -k 10 300 python -m pytest tests/test_model_gpu.py -x -q -k "resnet18" 2>&1 | tail -3
+for i in 1 2; do timeout -k 10 200 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "
+import sys,json; d=json.loads(sys.stdin.readline()); print('pool', d['ms_per_step'], {k:v.get('ms_per_step') for k,v in d.get('kernels',{}).items() if k in ('pool','pack','bn_bwd')})"; done
