@@ -22,6 +22,11 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- python3 $R/bench.py --steps 3 --wa
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
 rocprofv3 --pmc TCC_BUSY_avr TCC_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_tcc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_tcc.log 2>&1
 unset ICAMD_WGRAD_STREAM
+echo "== per-layer table and L2 requests of the 64->64 3x3 layer (implicit GEMM vs register-resident filter)"; date
+python3 $R/tools/bench_layers.py 256 10 > $O/layers.txt 2>&1
+for v in 0 1; do
+  ICAMD_CONV3X3_RESIDENT=$v ICAMD_WGRAD_HALO=$v rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_l2_c64_$v -- python3 $R/tools/one_layer.py 64 64 3 1 56 3 fwd,dgrad,wgrad > $O/pmc_l2_c64_$v.log 2>&1
+done
 date
 find $O -name "*.db" | head; find $O -name "*kernel_stats.csv" | head
 cd $R && python3 tools/pmc_traffic.py $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) 7 $O/r02_pmc_traffic.json resnet50 256
