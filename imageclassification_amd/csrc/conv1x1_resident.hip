@@ -1,0 +1,345 @@
+// Pointwise (1x1, stride 1) convolution forward / data gradient for K <= 512 with the FILTER RESIDENT IN REGISTERS
+// (reference: timm Bottleneck.conv1 / conv3 / downsample under model(samples) and loss.backward(),
+// /root/reference/engine.py:48,51,64,72):
+//   out[m][n] = sum_k A[m][k] * B[n][k]  (+ addend[m][n] [* mask bit]),  A = activations [M][K], B = filters [N][K], bf16.
+//
+// Why (profiles/README.md, round 2): on these layers conv_igemm.hip's 128x128 tiles are bound by L2 requests -- every tile
+// re-reads its 128 filter rows and every activation row is re-read once per channel tile -- and by per-tile fixed cost
+// (4 to 16 k-steps between a prologue and an epilogue).  Here, as in conv3x3_c64_resident_kernel:
+//   * a wave keeps its 16*NF filter rows for ALL of K in registers (NF * K/32 fragments <= 128 VGPRs), loaded once;
+//   * workgroups are persistent over a range of rows (two per CU, phases drift apart): only the activation tile goes
+//     through LDS, double-buffered by LDS-DMA, one s_barrier per tile; 16 B chunks XOR-swizzled by the row so that the
+//     per-lane read addresses are FOUR constants for the whole kernel -- buffer, fragment and k-step are the instruction's
+//     immediate offset -- and the tile loop contains no address arithmetic;
+//   * the four waves split the channels (WN = 4: the workgroup covers 64*NF channels, every wave reads the same activation
+//     fragments) or, for 64-channel outputs, the rows (WN = 1);
+//   * wave-private epilogue: MFMA layout -> [addend] -> bf16 -> two 16-row LDS patches -> 16 B row stores; BatchNorm partial
+//     sums stay in registers across tiles and leave as one partial row per workgroup.
+#include "common.h"
+#include "icamd_internal.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128_off(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+// KS: k-steps of 32 (K = 32*KS); NF: 16-channel fragments per wave; MF: 16-row fragments per wave; WN: waves across the
+// channels (4 / WN across the rows); ADD: addend epilogue compiled in.
+template <int KS, int NF, int MF, int WN, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
+  constexpr int WM = 4 / WN;
+  constexpr int TM = WM * MF * 16;              // rows per tile
+  constexpr int ROWB = KS * 64;                 // bytes per activation row
+  constexpr int A_BYTES = TM * ROWB;
+  constexpr int CW = NF * 16;                   // channels per wave
+  constexpr int EROW = CW * 2;                  // bytes per row of the epilogue patch (128 or 64)
+  constexpr int E_WAVE = 2 * 16 * EROW;         // two 16-row patches per wave
+  constexpr int NV = KS < 4 ? KS : 4;           // address variants (k-step bits that the row swizzle touches)
+  constexpr int RPI = 1024 / ROWB > 0 ? 1024 / ROWB : 1;   // rows per LDS-DMA instruction
+  constexpr int NINST = A_BYTES / 1024;         // LDS-DMA instructions per tile
+  constexpr int IPW = NINST / 4;                // per wave
+  static_assert(NINST % 4 == 0 && (NF == 2 || NF == 4) && KS >= 2 && KS <= 16, "configuration");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % WN, wm = wave / WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile_n = blockIdx.x % p.ntiles_n, split = blockIdx.x / p.ntiles_n;
+  const int n0 = (tile_n * WN + wn) * CW;       // this wave's first channel
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = (p.M < m_begin + p.rows_per_split) ? p.M : m_begin + p.rows_per_split;
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+  const unsigned lds_base = (unsigned)(uintptr_t)LPTR(smem);
+  unsigned char* const sE = smem + 2 * A_BYTES + wave * E_WAVE;
+
+  // Row swizzle of the 16 B chunks: position = chunk ^ sw(row); 128 B rows alternate between the two halves of the 256 B
+  // bank span, so their key is (row >> 1) & 7; wider rows all start on bank 0 and use row & 15.
+  auto sw = [](int row) { return ROWB == 128 ? (row >> 1) & 7 : row & 15; };
+
+  // ---- staging: instruction j of wave w is instruction q = j*4 + w of the tile: 1 KiB = RPI rows (or part of one row)
+  auto stage = [&](int m0, int buf) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int q = j * 4 + wave;
+      const int byte = q * 1024 + lane * 16;
+      const int row = byte / ROWB;
+      const int pos = (byte % ROWB) >> 4;
+      const int chunk = pos ^ sw(row);
+      const int m = m0 + row;
+      const bf16_t* src = m < m_end ? p.A + ((long long)m * p.K + chunk * 8) : zero;
+      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, 0);
+    }
+  };
+  int m0 = m_begin;
+  if (m0 < m_end) stage(m0, 0);                 // in flight under the filter loads
+
+  // ---- the filter: fragment (ks, j) = rows n0 + j*16 + fr, 8 input channels at ks*32 + fq*8
+  bf16x8 wf[KS][NF];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) wf[ks][j] = *(const bf16x8*)(p.B + (long long)(n0 + j * 16 + fr) * p.K + ks * 32 + fq * 8);
+  // arrived before the loop (the builtin: hipcc's wait-count bookkeeping sees it); also covers the first tile
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+
+  // ---- read addresses: row wm*MF*16 + fr (+16*i by immediate), chunk ks*4 + fq at position chunk ^ SW.  SW is constant
+  // per lane (fragments are 16 rows apart); its low two bits meet fq, its next two meet ks & 3: NV variants.
+  unsigned ra[NV];
+  {
+    const int row = wm * MF * 16 + fr;
+    const int SW = sw(row);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int pos = ((((v ^ (SW >> 2)) & (NV - 1)) << 2) | (fq ^ (SW & 3)));
+      ra[v] = lds_base + (unsigned)(row * ROWB + (pos << 4));
+    }
+  }
+
+  f32x2 s1[4], s2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
+  const bool want_stats = p.stats != nullptr;
+
+  constexpr int STORES = MF * (EROW / 64);       // row-store instructions per wave and tile
+  auto tile = [&](auto bufc, int tm0) {
+    constexpr int BUF = decltype(bufc)::value;
+    f32x4 acc[NF][MF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, KS>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      bf16x8 xf[MF];
+      static_for<0, MF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        xf[i] = lds_read128_off<BUF * A_BYTES + i * 16 * ROWB + (ks >> 2) * 256>(ra[ks & (NV - 1)]);
+      });
+      static_for<0, MF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[i]) : "n"(MF - 1 - i) : "memory");
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[i], acc[j][i], 0, 0, 0);
+      });
+    });
+
+    // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
+    const int mw = tm0 + wm * MF * 16;
+    // addend fragments (MFMA layout: this lane's 4 channels of row i*16 + fr): ALL loads are issued before the first use,
+    // so a tile pays one memory latency, not one per fragment
+    u32x2 av[ADD ? MF : 1][ADD ? NF : 1];
+    unsigned int ab[ADD ? MF : 1][ADD ? NF : 1];
+    bool has_add = false;
+    if constexpr (ADD) {
+      has_add = p.addend != nullptr;        // uniform
+      if (has_add) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const int m = mw + i * 16 + fr;
+          const int mc = m < p.M ? m : 0;
+          long long off = (long long)mc * p.N;
+          bool ok = true;
+          if (p.sub2_h > 0) {     // addend on the even pixel grid only (icamd_conv2d_dgrad_sub2)
+            const unsigned int n = fdiv((unsigned)mc, p.divHW);
+            const unsigned int rem = mc - n * (p.sub2_h * p.sub2_w);
+            const unsigned int hh = fdiv(rem, p.divW);
+            const unsigned int ww = rem - hh * p.sub2_w;
+            ok = ((hh | ww) & 1u) == 0u;
+            off = (((long long)n * ((p.sub2_h + 1) >> 1) + (hh >> 1)) * ((p.sub2_w + 1) >> 1) + (ww >> 1)) * p.N;
+          }
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const long long e = off + n0 + j * 16 + 4 * fq;
+            av[i][j] = *(const u32x2*)(p.addend + e);
+            ab[i][j] = ok ? 0xfu : 0u;
+            if (p.addend_bits != nullptr) ab[i][j] = ((unsigned int)p.addend_bits[e >> 3] >> (4 * (fq & 1))) & 0xfu;
+          }
+        }
+      }
+    }
+    static_for<0, (MF + 1) / 2>([&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = h * 2 + ii;
+        if (i < MF) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            f32x4 v = acc[j][i];
+            if constexpr (ADD) {
+              if (has_add) {
+                const u32x2 a = av[i][j];
+                const unsigned int bb = ab[i][j];
+                v[0] += (bb & 1u) ? bf16_lo(a[0]) : 0.f;
+                v[1] += (bb & 2u) ? bf16_hi(a[0]) : 0.f;
+                v[2] += (bb & 4u) ? bf16_lo(a[1]) : 0.f;
+                v[3] += (bb & 8u) ? bf16_hi(a[1]) : 0.f;
+              }
+            }
+            u32x2 pk;
+            pk[0] = pack_bf16x2(v[0], v[1]);
+            pk[1] = pack_bf16x2(v[2], v[3]);
+            const int slot = j * 4 + fq;          // 8 B slot of the row; 16 B chunk = slot >> 1
+            const int ch = NF == 4 ? (((slot >> 1) ^ fr) & 7) : (((slot >> 1) ^ (fr >> 2)) & 3);
+            *(u32x2*)(sE + ii * 16 * EROW + fr * EROW + (ch << 4) + ((slot & 1) << 3)) = pk;
+          }
+        }
+      }
+      constexpr int LPR = EROW / 16;              // lanes per row: 8 or 4
+      constexpr int RPR = 64 / LPR;               // rows per read instruction: 8 or 16
+#pragma unroll
+      for (int r = 0; r < 32 / RPR; ++r) {
+        const int prow = r * RPR + lane / LPR;    // row of the two-patch pair, 0..31
+        const int i = h * 2 + (prow >> 4);
+        if (i < MF) {
+          const int rr = prow & 15, c = lane % LPR;
+          const int ch = NF == 4 ? ((c ^ rr) & 7) : ((c ^ (rr >> 2)) & 3);
+          const u32x4 o = *(const u32x4*)(sE + prow * EROW + (ch << 4));
+          const int m = mw + i * 16 + rr;
+          if (m < m_end) {
+            *(u32x4*)(p.out + (long long)m * p.N + n0 + c * 8) = o;
+            if (want_stats) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f32x2 v = {bf16_lo(o[e]), bf16_hi(o[e])};
+                s1[e] += v;
+                s2[e] = __builtin_elementwise_fma(v, v, s2[e]);
+              }
+            }
+          }
+        }
+      }
+    });
+  };
+
+  for (; m0 < m_end; m0 += 2 * TM) {
+    // this tile has landed for every wave and every wave is done with the other buffer; behind the tile's loads in the
+    // queue: the previous tile's STORES row stores (full tiles always issue all of them; a ragged tile is a range's last)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ADD ? 0 : STORES) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (m0 + TM < m_end) stage(m0 + TM, 1);
+    tile(std::integral_constant<int, 0>{}, m0);
+    if (m0 + TM >= m_end) break;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ADD ? 0 : STORES) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (m0 + 2 * TM < m_end) stage(m0 + 2 * TM, 0);
+    tile(std::integral_constant<int, 1>{}, m0 + TM);
+  }
+
+  if (want_stats) {
+    // one partial row per workgroup (row `split` of the [ceil(M/128)] table); rows no workgroup owns are zero
+    __syncthreads();
+    constexpr int LPR = EROW / 16, G = 64 / LPR;   // lane groups per wave that share a channel group
+    float* red = (float*)smem;                      // [WM * G][2][WN * CW]
+    const int c = lane % LPR, g = wm * G + lane / LPR;
+    constexpr int COLS = WN * CW;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[(g * 2 + 0) * COLS + wn * CW + c * 8 + 2 * e] = s1[e][0];
+      red[(g * 2 + 0) * COLS + wn * CW + c * 8 + 2 * e + 1] = s1[e][1];
+      red[(g * 2 + 1) * COLS + wn * CW + c * 8 + 2 * e] = s2[e][0];
+      red[(g * 2 + 1) * COLS + wn * CW + c * 8 + 2 * e + 1] = s2[e][1];
+    }
+    __syncthreads();
+    const int nrows = (p.M + 127) / 128, S = gridDim.x / p.ntiles_n;
+    for (int idx = tid; idx < 2 * COLS; idx += 256) {
+      const int which = idx / COLS, cc = idx - which * COLS;
+      float s = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < WM * G; ++k) s += red[(k * 2 + which) * COLS + cc];
+      const int col = tile_n * COLS + cc;
+      p.stats[((long long)split * 2 + which) * p.N + col] = s;
+      for (int r = split + S; r < nrows; r += S) p.stats[((long long)r * 2 + which) * p.N + col] = 0.f;
+    }
+  }
+}
+
+int mode() {
+  static const int m = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e ? atoi(e) : 1; }();
+  return m;
+}
+
+struct Config { int ks, nf, mf, wn; };
+
+// the instantiated shapes: (K, channels per workgroup)
+bool pick(int N, int K, Config* c) {
+  if (K == 64 && N % 256 == 0) { *c = {2, 4, 4, 4}; return true; }
+  if (K == 64 && N == 64) { *c = {2, 4, 1, 1}; return true; }
+  if (K == 128 && N % 256 == 0) { *c = {4, 4, 4, 4}; return true; }
+  if (K == 256 && N % 256 == 0) { *c = {8, 4, 2, 4}; return true; }
+  // (K = 256, N = 64 -- four waves of 16 rows x 64 channels, the whole filter in each -- was built and measured: it ties
+  // conv_igemm in isolation (102 us, 256 -> 64 at 56x56) and loses in-model, so it is not instantiated)
+  if (K == 256 && N % 128 == 0) { *c = {8, 2, 4, 4}; return true; }
+  if (K == 512 && N % 128 == 0) { *c = {16, 2, 2, 4}; return true; }
+  return false;
+}
+
+template <int KS, int NF, int MF, int WN>
+int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
+  if (p.addend != nullptr)
+    hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  return icamd_launch_status();
+}
+
+}  // namespace
+
+bool icamd_pw_resident_wanted(long long M, int N, int K) {
+  Config c;
+  if (mode() == 0 || M <= 0 || M >= (1ll << 30) || !pick(N, K, &c)) return false;
+  // persistent workgroups need rows to amortise the filter load: at least ~8 tiles per workgroup at 512 workgroups
+  const int tm = (4 / c.wn) * c.mf * 16;
+  const int ntn = N / (c.wn * c.nf * 16);
+  if (mode() == 2) return true;
+  // K = 512 leaves room for 32 filter rows per wave only: measured on MI355X (batch 256) it wins on the 7x7 layers and on
+  // 512 -> 256 at 28x28, ties at N = 128 and LOSES at N = 1024, M = 50176 (64 -> 83 us), so that one stays on conv_igemm
+  if (K == 512 && !(M < 32768 || N == 256)) return false;
+  return M / tm * ntn >= 8 * 512;
+}
+
+int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
+  Config c;
+  if (!pick(p.N, p.K, &c)) return ICAMD_ERR_UNSUPPORTED;
+  const int tm = (4 / c.wn) * c.mf * 16;
+  p.ntiles_n = p.N / (c.wn * c.nf * 16);
+  // two workgroups per CU; the statistics table has ceil(M/128) rows, one per split at most
+  int S = (512 + p.ntiles_n - 1) / p.ntiles_n;
+  const int cap_tiles = (p.M + tm - 1) / tm, cap_rows = (p.M + 127) / 128;
+  if (S > cap_tiles) S = cap_tiles;
+  if (p.stats != nullptr && S > cap_rows) S = cap_rows;
+  if (S < 1) S = 1;
+  int rows = (p.M + S - 1) / S;
+  rows = (rows + tm - 1) / tm * tm;
+  p.rows_per_split = rows;
+  S = (p.M + rows - 1) / rows;
+  if (p.sub2_h > 0) {
+    p.divHW = make_fastdiv((unsigned)(p.sub2_h * p.sub2_w));
+    p.divW = make_fastdiv((unsigned)p.sub2_w);
+  }
+  const int grid = S * p.ntiles_n;
+  if (c.ks == 2 && c.wn == 4) return launch<2, 4, 4, 4>(p, grid, stream);
+  if (c.ks == 2) return launch<2, 4, 1, 1>(p, grid, stream);
+  if (c.ks == 4) return launch<4, 4, 4, 4>(p, grid, stream);
+  if (c.ks == 8 && c.nf == 4) return launch<8, 4, 2, 4>(p, grid, stream);
+  if (c.ks == 8) return launch<8, 2, 4, 4>(p, grid, stream);
+  return launch<16, 2, 2, 4>(p, grid, stream);
+}

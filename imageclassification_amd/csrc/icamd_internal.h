@@ -78,6 +78,22 @@ int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream);
 // true when the 256x256-tile kernel is expected to beat the 128x128 implicit-GEMM kernel for this problem
 bool icamd_gemm_nt_wanted(long long M, int N, int K);
 
+// Pointwise convolution with the filter resident in registers (conv1x1_resident.hip): out[m][n] = sum_k A[m][k] * B[n][k]
+struct PwResidentParams {
+  const bf16_t* A;       // [M][K]
+  const bf16_t* B;       // [N][K]
+  bf16_t* out;           // [M][N]
+  const bf16_t* addend;  // optional [M][N] (or the even-grid form, see sub2_h)
+  const unsigned char* addend_bits;   // optional 1 bit per addend element
+  float* stats;          // optional [ceil(M/128)][2][N]; one partial row per workgroup, the other rows zero
+  int M, N, K;
+  int sub2_h, sub2_w;    // > 0: addend is [.][ceil(h/2)][ceil(w/2)][N], added at even (h, w)
+  FastDiv divHW, divW;   // filled by the launcher
+  int rows_per_split, ntiles_n;   // filled by the launcher
+};
+bool icamd_pw_resident_wanted(long long M, int N, int K);
+int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream);
+
 // Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
 struct WgradParams {
   const bf16_t* x;    // [N, IH, IW, Cin]

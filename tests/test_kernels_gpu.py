@@ -214,6 +214,30 @@ def test_pointwise_large_tile_gemm(lib):
     _run_large_pointwise(lib, LARGE_POINTWISE)
 
 
+def test_pointwise_register_resident_filter_every_shape():
+    """conv1x1_resident.hip (filter in registers, persistent workgroups) is selected by problem size; ICAMD_PW_RESIDENT=2
+    routes every eligible (K, N) to it, so each instantiated shape runs the forward (with BatchNorm statistics), the data
+    gradient (plain, + addend, + mask-bit addend) and the even-grid addend on small problems, plus two problems large enough
+    for several tiles per workgroup (both LDS buffers).  Child process: the switch is read once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_kernels_gpu as T\n"
+        "from imageclassification_amd import hip\n"
+        "lib = hip.load()\n"
+        "T._run_large_pointwise(lib, [(2, 9, 9, 64, 256), (3, 7, 5, 64, 64), (2, 10, 10, 128, 512), (2, 8, 8, 256, 1024),\n"
+        "                             (2, 8, 8, 1024, 256), (1, 13, 11, 256, 128), (2, 6, 6, 512, 2048),\n"
+        "                             (64, 28, 28, 64, 256), (32, 56, 56, 256, 64)])\n"
+        "for case in [(2, 12, 12, 256, 128, 1, 1, 0), (1, 8, 8, 512, 256, 1, 1, 0), (3, 7, 7, 512, 256, 1, 1, 0)]:\n"
+        "    T.test_conv_dgrad_addend_on_even_grid(lib, case)\n"
+        "print('forced-ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ICAMD_PW_RESIDENT="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_pointwise_large_tile_gemm_forced_small_k():
     """ICAMD_GEMM_NT=2 routes every eligible pointwise problem through gemm_nt.hip: covers 1-, 2- and 3-stage K loops and
     tiles that are mostly padding.  The routing switch is read once per process, hence the child process."""
