@@ -253,7 +253,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
   const int st = d->stride;
   // (with an addend the persistent kernel pays one exposed memory latency per 32- or 64-row tile at two workgroups per CU:
   // measured in-model, data gradients 4.27 -> 4.59 ms; those launches stay on conv_igemm unless ICAMD_PW_RESIDENT=2)
-  static const bool pw_addend = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e && atoi(e) == 2; }();
+  static const bool pw_addend = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e && atoi(e) >= 2; }();
   if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && f == nullptr && gelu_z == nullptr &&
       (addend == nullptr || pw_addend) && !(addend_bits != nullptr && addend_sub2) &&
       icamd_pw_resident_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
-  const bool want_stats = p.stats != nullptr;
+  const bool want_stats = !ADD && p.stats != nullptr;   // the launcher never pairs statistics with an addend
 
   constexpr int STORES = MF * (EROW / 64);       // row-store instructions per wave and tile
   auto tile = [&](auto bufc, int tm0) {
@@ -124,25 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     for (int j = 0; j < NF; ++j)
 #pragma unroll
       for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    static_for<0, KS>([&](auto ksc) {
-      constexpr int ks = decltype(ksc)::value;
-      bf16x8 xf[MF];
-      static_for<0, MF>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        xf[i] = lds_read128_off<BUF * A_BYTES + i * 16 * ROWB + (ks >> 2) * 256>(ra[ks & (NV - 1)]);
-      });
-      static_for<0, MF>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[i]) : "n"(MF - 1 - i) : "memory");
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[i], acc[j][i], 0, 0, 0);
-      });
-    });
-
-    // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
+    // addend fragments (MFMA layout: this lane's 4 channels of row i*16 + fr): ALL loads are issued before the tile's
+    // MFMAs, so their latency hides under them (the ADD form carries no statistics: those registers pay for these)
     const int mw = tm0 + wm * MF * 16;
-    // addend fragments (MFMA layout: this lane's 4 channels of row i*16 + fr): ALL loads are issued before the first use,
-    // so a tile pays one memory latency, not one per fragment
     u32x2 av[ADD ? MF : 1][ADD ? NF : 1];
     unsigned int ab[ADD ? MF : 1][ADD ? NF : 1];
     bool has_add = false;
@@ -173,6 +157,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
         }
       }
     }
+    static_for<0, KS>([&](auto ksc) {
+      constexpr int ks = decltype(ksc)::value;
+      bf16x8 xf[MF];
+      static_for<0, MF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        xf[i] = lds_read128_off<BUF * A_BYTES + i * 16 * ROWB + (ks >> 2) * 256>(ra[ks & (NV - 1)]);
+      });
+      static_for<0, MF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[i]) : "n"(MF - 1 - i) : "memory");
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], xf[i], acc[j][i], 0, 0, 0);
+      });
+    });
+
+    // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
     static_for<0, (MF + 1) / 2>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
 #pragma unroll
@@ -214,12 +214,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           const int m = mw + i * 16 + rr;
           if (m < m_end) {
             *(u32x4*)(p.out + (long long)m * p.N + n0 + c * 8) = o;
-            if (want_stats) {
+            if constexpr (!ADD) {
+              if (want_stats) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const f32x2 v = {bf16_lo(o[e]), bf16_hi(o[e])};
-                s1[e] += v;
-                s2[e] = __builtin_elementwise_fma(v, v, s2[e]);
+                for (int e = 0; e < 4; ++e) {
+                  const f32x2 v = {bf16_lo(o[e]), bf16_hi(o[e])};
+                  s1[e] += v;
+                  s2[e] = __builtin_elementwise_fma(v, v, s2[e]);
+                }
               }
             }
           }
@@ -318,7 +320,7 @@ bool icamd_pw_resident_wanted(long long M, int N, int K) {
 
 int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
   Config c;
-  if (!pick(p.N, p.K, &c)) return ICAMD_ERR_UNSUPPORTED;
+  if (!pick(p.N, p.K, &c) || (p.stats != nullptr && p.addend != nullptr)) return ICAMD_ERR_UNSUPPORTED;
   const int tm = (4 / c.wn) * c.mf * 16;
   p.ntiles_n = p.N / (c.wn * c.nf * 16);
   // two workgroups per CU; the statistics table has ceil(M/128) rows, one per split at most
