@@ -18,7 +18,8 @@ int icamd_bn_bwd_rows_per_block(long long rows, int C);
 int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
                         const unsigned char* maskbits, long long rows, int C, int relu, int accumulate, float* part,
-                        double* chunks, float* c1c2, hipStream_t s);
+                        double* chunks, float* c1c2, hipStream_t s, const unsigned char* pool_idx = nullptr,
+                        int pool_ih = 0, int pool_iw = 0);
 int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, const bf16_t* yA, const float* meanA,
                              const float* invstdA, const float* scaleA, float* dgammaA, float* dbetaA, bf16_t* dyA,
                              const bf16_t* yB, const float* meanB, const float* invstdB, const float* scaleB, float* dgammaB,
@@ -516,6 +517,32 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
   return icamd_bn_bwd_launch((const bf16_t*)dout, (const bf16_t*)act, (const bf16_t*)y, mean, invstd, scale, shift, dgamma,
                              dbeta, (bf16_t*)dy, (bf16_t*)gout, maskbits, rows, C, relu, accumulate, part, chunks, c1c2,
                              (hipStream_t)stream);
+}
+
+int icamd_bn_bwd_maxpool3x3s2(const void* dout_pooled, const uint8_t* idx, const void* y, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                              void* dy, int N, int IH, int IW, int C, int accumulate, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (dout_pooled == nullptr || idx == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr ||
+      shift == nullptr || dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || N <= 0 || IH <= 0 ||
+      IW <= 0 || C <= 0 || C % 8 != 0)
+    return ICAMD_ERR_BAD_ARG;
+  const long long rows = (long long)N * IH * IW;
+  const size_t need = icamd_bn_bwd_workspace_bytes(rows, C);
+  if (workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  if (C > 4096) return ICAMD_ERR_UNSUPPORTED;
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const long long nblk = (rows + rpb - 1) / rpb;
+  char* ws = (char*)workspace;
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(C);
+  float* part = (float*)ws;
+  ws += align_up((size_t)nblk * 2 * C * sizeof(float), 256);
+  float* c1c2 = (float*)ws;
+  return icamd_bn_bwd_launch((const bf16_t*)dout_pooled, nullptr, (const bf16_t*)y, mean, invstd, scale, shift, dgamma, dbeta,
+                             (bf16_t*)dy, nullptr, nullptr, rows, C, /*relu=*/1, accumulate, part, chunks, c1c2,
+                             (hipStream_t)stream, idx, IH, IW);
 }
 
 int icamd_bn_bwd_dual(const void* dout, const uint8_t* maskbits, const void* yA, const float* meanA, const float* invstdA,

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "icamd_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -190,6 +191,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Max-pool backward folded into the BatchNorm backward that follows it (the ResNet stem: conv -> BN -> ReLU -> max-pool):
+// with pg.idx set, `dout` is the gradient of the POOLED map [N][OH][OW][C] and the gradient of full-resolution pixel `row`
+// is gathered on the fly -- the sum over the (<= 4) 3x3/s2/p1 windows that cover it and whose recorded argmax it is, rounded
+// to bf16 exactly as icamd_maxpool3x3s2_bwd would have stored it -- so the 4x larger full-resolution gradient is never
+// written or read.
+struct PoolGather {
+  const unsigned char* idx;   // nullptr: no pooling in front, dout is read directly
+  int IH, IW, OH, OW;
+  FastDiv dIW, dIH;
+};
+
+__device__ __forceinline__ u32x4 pool_gather8(const bf16_t* __restrict__ dout, const PoolGather& pg, unsigned int row,
+                                              unsigned int cpr, unsigned int cg) {
+  const unsigned int t1 = fdiv(row, pg.dIW);
+  const int w = (int)(row - t1 * pg.IW);
+  const unsigned int n = fdiv(t1, pg.dIH);
+  const int h = (int)(t1 - n * pg.IH);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const int oh_lo = h >> 1, oh_hi = (h + 1) >> 1, ow_lo = w >> 1, ow_hi = (w + 1) >> 1;
+  for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+    if (oh >= pg.OH) continue;
+    const int r = h - (oh * 2 - 1);
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      if (ow >= pg.OW) continue;
+      const unsigned int code4 = (unsigned)(r * 3 + (w - (ow * 2 - 1))) * 0x01010101u;
+      const unsigned int o = ((n * pg.OH + oh) * pg.OW + ow) * cpr + cg;
+      const u32x2 iv = ((const u32x2*)pg.idx)[o];
+      const u32x4 d = ((const u32x4*)dout)[o];
+      const unsigned int m0 = iv[0] ^ code4, m1 = iv[1] ^ code4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned int mb = ((e < 4 ? m0 : m1) >> ((e & 3) * 8)) & 0xffu;
+        const float dv = (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]);
+        acc[e] += mb == 0u ? dv : 0.f;
+      }
+    }
+  }
+  u32x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) out[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // BN backward, pass 1: per-channel partial sums of g and g*xhat, g = dout * [act > 0]
 //   act == nullptr && relu : mask recomputed from y*scale+shift > 0 (no residual in front of the ReLU)
 // rows are pixels; block handles `rows_per_block` rows; part[blk][2][C]
@@ -199,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ part,
                                                             const unsigned char* __restrict__ maskbits, long long rows, int C,
-                                                            int rows_per_block, int relu) {
+                                                            int rows_per_block, int relu, const PoolGather pg) {
   __shared__ float red[256 * 16];
   const int cpr = C >> 3;                 // 8-channel groups per row
   const int tid = threadIdx.x;
@@ -220,7 +267,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
       for (int e = 0; e < 8; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
       for (long long r = r0 + rl; r < r1; r += rlanes) {
         const long long off = r * cpr + cg0 + cgi;
-        const u32x4 d = ((const u32x4*)dout)[off];
+        const u32x4 d = pg.idx != nullptr ? pool_gather8(dout, pg, (unsigned)r, (unsigned)cpr, (unsigned)(cg0 + cgi))
+                                          : ((const u32x4*)dout)[off];
         const u32x4 yv = ((const u32x4*)y)[off];
         float g[8], yy[8];
 #pragma unroll
@@ -277,7 +325,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ shift, const float* __restrict__ c1,
                                                            const float* __restrict__ c2, bf16_t* __restrict__ dy,
                                                            bf16_t* __restrict__ gout, const unsigned char* __restrict__ maskbits,
-                                                           long long nvec, int cpr, int relu, int reverse) {
+                                                           long long nvec, int cpr, int relu, int reverse,
+                                                           const PoolGather pg, const FastDiv dcpr) {
   // `reverse`: walk the tensors from the END.  The reduce pass that ran just before streamed dout and y front to back, so
   // their tails are what the 256 MB Infinity Cache (and L2) still hold: reading back to front meets those lines first.
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -292,7 +341,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
   for (; k0 < nvec; k0 += stride) {
     const long long i = reverse ? nvec - 1 - k0 : k0;
-    const u32x4 d = ((const u32x4*)dout)[i];
+    u32x4 d;
+    if (pg.idx != nullptr) {
+      const unsigned int row = fdiv((unsigned)i, dcpr);
+      d = pool_gather8(dout, pg, row, (unsigned)cpr, (unsigned)i - row * (unsigned)cpr);
+    } else {
+      d = ((const u32x4*)dout)[i];
+    }
     const u32x4 yv = ((const u32x4*)y)[i];
     float g[8], yy[8];
 #pragma unroll
@@ -825,12 +880,21 @@ int icamd_bn_bwd_rows_per_block(long long rows, int C) {
 int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, const float* mean, const float* invstd,
                         const float* scale, const float* shift, float* dgamma, float* dbeta, bf16_t* dy, bf16_t* gout,
                         const unsigned char* maskbits, long long rows, int C, int relu, int accumulate, float* part,
-                        double* chunks, float* c1c2, hipStream_t s) {
+                        double* chunks, float* c1c2, hipStream_t s, const unsigned char* pool_idx, int pool_ih, int pool_iw) {
   if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  PoolGather pg;
+  memset(&pg, 0, sizeof(pg));
+  if (pool_idx != nullptr) {   // dout is the pooled map's gradient: rows = N * pool_ih * pool_iw full-resolution pixels
+    if (rows * (C / 8) >= (1ll << 31) || pool_ih < 1 || pool_iw < 1 || rows % ((long long)pool_ih * pool_iw) != 0)
+      return ICAMD_ERR_BAD_ARG;
+    pg.idx = pool_idx; pg.IH = pool_ih; pg.IW = pool_iw; pg.OH = (pool_ih - 1) / 2 + 1; pg.OW = (pool_iw - 1) / 2 + 1;
+    pg.dIW = make_fastdiv((unsigned)pool_iw); pg.dIH = make_fastdiv((unsigned)pool_ih);
+  }
+  const FastDiv dcpr = make_fastdiv((unsigned)(C / 8));
   const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
   const int nblk = (int)((rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dout, act, y, mean, invstd, scale, shift,
-                     part, maskbits, rows, C, rpb, relu);
+                     part, maskbits, rows, C, rpb, relu, pg);
   int rc = icamd_launch_status();
   if (rc) return rc;
   float* c1 = c1c2;
@@ -847,7 +911,7 @@ int icamd_bn_bwd_launch(const bf16_t* dout, const bf16_t* act, const bf16_t* y, 
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, dout, act, y, mean, invstd,
-                     scale, shift, c1, c2, dy, gout, maskbits, nvec, C / 8, relu, bn_reverse());
+                     scale, shift, c1, c2, dy, gout, maskbits, nvec, C / 8, relu, bn_reverse(), pg, dcpr);
   return icamd_launch_status();
 }
 
@@ -901,7 +965,7 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
   }
   const long long nvec = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_grid(nvec, C / 8)), dim3(256), 0, s, g, (const bf16_t*)nullptr, y,
-                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, (const unsigned char*)nullptr, nvec, C / 8, 0, 0);
+                     mean, invstd, scale, scale, c1, c2, dy, (bf16_t*)nullptr, (const unsigned char*)nullptr, nvec, C / 8, 0, 0, PoolGather{}, make_fastdiv((unsigned)(C / 8)));
   return icamd_launch_status();
 }
 

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "icamd_bn_apply_res_bn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P]),
     "icamd_bn_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "icamd_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "icamd_bn_bwd_maxpool3x3s2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "icamd_bn_bwd_dual": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int,
                                   _P, _P, c_size_t, _P]),
     "icamd_bn_bwd_apply_workspace_bytes": (c_size_t, [c_int]),

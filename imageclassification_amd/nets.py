@@ -28,6 +28,10 @@ _FUSED_BNBWD = os.environ.get("ICAMD_FUSED_BNBWD", "0") == "1"
 _WGRAD_STREAM = os.environ.get("ICAMD_WGRAD_STREAM", "1") != "0"
 _DUAL_BNBWD = os.environ.get("ICAMD_DUAL_BNBWD", "1") != "0"
 _SUB2_SHORTCUT = os.environ.get("ICAMD_SUB2_SHORTCUT", "1") != "0"
+# stem max-pool backward folded into the BatchNorm backward (icamd_bn_bwd_maxpool3x3s2, bit-identical): measured on MI355X it
+# trades 0.20 ms of pooling backward for +0.27 ms of BatchNorm backward (the gather of <= 4 windows per pixel, done in both
+# passes, is bound by L1 / texture-address requests, not by the HBM bytes it saves), so it is opt-in
+_FUSED_POOL_BWD = os.environ.get("ICAMD_FUSED_POOL_BWD", "0") == "1"
 BN_MOMENTUM = 0.1
 
 ARCHS = {
@@ -802,9 +806,18 @@ class ResNet(PicklableModel):
 
         # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
         d0 = self.stem_conv.desc(N, ws["H"], ws["W"])
-        hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
         yk = next_y()
-        bn_bwd(self.stem_bn, DA, None, ws["y0"], ypool[yk], None, True)
+        if _FUSED_POOL_BWD:
+            # max-pool backward folded into both BatchNorm-backward passes: the 112x112 gradient is never materialised
+            bn0 = self.stem_bn
+            st = self.stat_arena.data_ptr() + 4 * bn0.stat_offset
+            c = bn0.c
+            hip.check(lib.icamd_bn_bwd_maxpool3x3s2(dout, ws["p0_idx"].data_ptr(), ws["y0"].data_ptr(), st, st + 4 * c,
+                                                    st + 8 * c, st + 12 * c, self._gf(bn0.weight), self._gf(bn0.bias),
+                                                    ypool[yk], N, d0.OH, d0.OW, c, acc, bws, bwb, s), "stem maxpool + bn bwd")
+        else:
+            hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
+            bn_bwd(self.stem_bn, DA, None, ws["y0"], ypool[yk], None, True)
         wgrad(self.stem_conv, ws["x8"].data_ptr(), ypool[yk], N, ws["H"], ws["W"], ybuf=yk)
         for k in range(len(pending)):     # every buffer is free again when the next backward starts
             pending[k] = None

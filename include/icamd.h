@@ -149,6 +149,16 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
                  const float* scale, const float* shift, float* dgamma, float* dbeta, void* dy, void* gout,
                  const uint8_t* maskbits, long long rows, int C, int relu, int accumulate, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* The same for the BatchNorm + ReLU in front of a 3x3 / stride 2 / pad 1 max-pool (ResNet stem, fused forward:
+ * icamd_bn_relu_maxpool3x3s2_fwd): dout_pooled is the gradient of the POOLED map [N][OH][OW][C], idx its recorded argmax;
+ * the max-pool backward is folded into both passes (the full-resolution gradient [N][IH][IW][C] is never materialised;
+ * bit-identical to icamd_maxpool3x3s2_bwd followed by icamd_bn_bwd with relu = 1 and the mask recomputed from y).
+ * Workspace: icamd_bn_bwd_workspace_bytes(N*IH*IW, C). */
+int icamd_bn_bwd_maxpool3x3s2(const void* dout_pooled, const uint8_t* idx, const void* y, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                              void* dy, int N, int IH, int IW, int C, int accumulate, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* Two BatchNorm backward passes over ONE masked output gradient g = dout * maskbits: the last BatchNorm of a residual block
  * (conv output yA) and the BatchNorm of its projection shortcut (yB), /root/reference's timm Bottleneck/BasicBlock with
  * `downsample`.  Same results as two icamd_bn_bwd calls (relu = 1, maskbits given); dout and the bits are read twice instead

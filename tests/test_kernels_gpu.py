@@ -669,6 +669,51 @@ def test_maxpool(lib, shape):
     assert R.max_bf16_ulp(got, rdx) <= 1.0 and R.rel_l2(got, rdx) <= 1e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (3, 9, 7, 64), (2, 14, 14, 128), (1, 1, 1, 64), (5, 12, 10, 64)])
+def test_bn_bwd_with_maxpool_backward_folded_in_is_bit_identical(lib, shape):
+    """icamd_bn_bwd_maxpool3x3s2 == icamd_maxpool3x3s2_bwd followed by icamd_bn_bwd (relu = 1, mask recomputed from y):
+    input gradient, dgamma and dbeta bit for bit (the ResNet stem's backward; odd sizes, windows cut by the border)."""
+    hip = _hip()
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(130)
+    y = to_dev_bf16(rnd_bf16(N, H, W, C, seed=131))
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    yf = y.float().reshape(-1, C)
+    mean = yf.mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5)).contiguous()
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    s = hip.stream_ptr()
+    pooled = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
+    idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=DEV)
+    assert lib.icamd_bn_relu_maxpool3x3s2_fwd(hip.ptr(y), hip.ptr(scale), hip.ptr(shift), hip.ptr(pooled), hip.ptr(idx), N, H, W,
+                                              C, s) == 0
+    dout = to_dev_bf16(rnd_bf16(N, OH, OW, C, seed=132))
+    rows = N * H * W
+    wsb = lib.icamd_bn_bwd_workspace_bytes(rows, C)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    # two steps
+    da = torch.empty_like(y)
+    dy1 = torch.empty_like(y)
+    dg1 = torch.empty(C, device=DEV); db1 = torch.empty(C, device=DEV)
+    assert lib.icamd_maxpool3x3s2_bwd(hip.ptr(dout), hip.ptr(idx), hip.ptr(da), N, H, W, C, s) == 0
+    assert lib.icamd_bn_bwd(hip.ptr(da), None, hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(shift),
+                            hip.ptr(dg1), hip.ptr(db1), hip.ptr(dy1), None, None, rows, C, 1, 0, hip.ptr(ws), wsb, s) == 0
+    # folded
+    dy2 = torch.empty_like(y)
+    dg2 = torch.empty(C, device=DEV); db2 = torch.empty(C, device=DEV)
+    assert lib.icamd_bn_bwd_maxpool3x3s2(hip.ptr(dout), hip.ptr(idx), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale),
+                                         hip.ptr(shift), hip.ptr(dg2), hip.ptr(db2), hip.ptr(dy2), N, H, W, C, 0, hip.ptr(ws), wsb,
+                                         s) == 0
+    sync()
+    assert torch.equal(dy1, dy2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    assert lib.icamd_bn_bwd_maxpool3x3s2(hip.ptr(dout), None, hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale),
+                                         hip.ptr(shift), hip.ptr(dg2), hip.ptr(db2), hip.ptr(dy2), N, H, W, C, 0, hip.ptr(ws), wsb,
+                                         s) == 1
+
+
 def test_bn_apply_with_shortcut_batchnorm_is_bit_identical(lib):
     """Residual given as the raw shortcut conv output + its BatchNorm coefficients == BatchNorm-apply on the shortcut
     followed by the residual BatchNorm-apply (output and ReLU mask bits)."""
