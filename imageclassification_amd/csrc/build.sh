@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../include"
 OBJS=""
 PIDS=""
-for f in conv_igemm conv3x3_halo conv1x1_resident conv_wgrad norm_pool loss_optim token_ops attention dwconv gemm_nt image_ops collective capi; do
+for f in conv_igemm conv3x3_halo conv1x1_resident conv_stem conv_wgrad norm_pool loss_optim token_ops attention dwconv gemm_nt image_ops collective capi; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ icamd_internal.h -nt build/$f.o ] || [ ../../include/icamd.h -nt build/$f.o ]; then
     mkdir -p build
     rm -f build/$f.o   # a failed compile must not leave a stale object for the link step

@@ -94,6 +94,17 @@ struct PwResidentParams {
 bool icamd_pw_resident_wanted(long long M, int N, int K);
 int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream);
 
+// ResNet stem forward with the filter resident in registers (conv_stem.hip)
+struct StemParams {
+  const bf16_t* x;   // [N][H][W+8][4]
+  const bf16_t* w;   // [64][8][8][4]
+  bf16_t* y;         // [N][OH][OW][64]
+  float* stats;      // optional [ceil(M/128)][2][64]
+  int N, H, W, OH, OW;
+};
+bool icamd_stem_resident_wanted(int N, int H, int W, int Cout);
+int icamd_stem_resident_launch(StemParams& p, hipStream_t stream);
+
 // Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
 struct WgradParams {
   const bf16_t* x;    // [N, IH, IW, Cin]

@@ -810,7 +810,10 @@ def test_pack_input_rgb4_stem_layout(lib, mode):
     assert lib.icamd_pack_input_rgb4(hip.ptr(xdev), hip.ptr(out), B, 3, H, 13, 0, 1.0, 0, 0, 0, 0, hip.stream_ptr()) != 0
 
 
-@pytest.mark.parametrize("case", [(2, 16, 16, 64), (3, 30, 34, 64), (1, 64, 64, 72), (2, 9, 8, 64)])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64), (3, 30, 34, 64), (1, 64, 64, 72), (2, 9, 8, 64),
+                                  # output widths 64..128 in steps of 16, even output height: conv_stem.hip (filter resident in
+                                  # registers, two output rows per tile); 10 x 224^2 = 560 tiles > 512 workgroups
+                                  (2, 128, 128, 64), (1, 160, 160, 64), (2, 192, 192, 64), (10, 224, 224, 64), (1, 132, 256, 64)])
 def test_stem7x7s2_fwd_and_wgrad(lib, case):
     """ResNet stem (7x7 stride 2 pad 3, timm resnet conv1) on the rgb4 layout against torch's convolution of the same bf16
     values: output and BatchNorm statistics partials, fused bias + ReLU (eval form), and the weight gradient, whose padding
