@@ -872,6 +872,10 @@ size_t icamd_stem7x7s2_wgrad_workspace_bytes(int N, int H, int W, int Cout) {
   if (M >= (1ll << 30)) return 0;
   int S = 1, rows = 0;
   icamd_wgrad_plan((int)M, Cout, 256, &S, &rows);
+  if (icamd_stem_resident_wanted(N, H, W, Cout)) {
+    const int S2 = icamd_stem_wgrad_resident_splits(N, H);
+    if (S2 > S) S = S2;
+  }
   return (size_t)S * Cout * (256 + 1) * sizeof(float);
 }
 
@@ -882,6 +886,15 @@ int icamd_stem7x7s2_wgrad(const void* x4, const void* dy, float* dw, int accumul
   const size_t need = icamd_stem7x7s2_wgrad_workspace_bytes(N, H, W, Cout);
   if (need == 0) return ICAMD_ERR_BAD_ARG;
   if (workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  if (icamd_stem_resident_wanted(N, H, W, Cout)) {   // conv_stem.hip
+    StemWgradParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.x = (const bf16_t*)x4; sp.dy = (const bf16_t*)dy; sp.slab = (float*)workspace; sp.N = N; sp.H = H; sp.W = W;
+    const int S = icamd_stem_wgrad_resident_splits(N, H);
+    const int rc = icamd_stem_wgrad_resident_launch(sp, S, (hipStream_t)stream);
+    if (rc) return rc;
+    return icamd_slab_reduce_launch(sp.slab, dw, (long long)Cout * 256, S, accumulate, (hipStream_t)stream, 1);
+  }
   WgradParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const bf16_t*)x4; p.dy = (const bf16_t*)dy; p.slab = (float*)workspace;

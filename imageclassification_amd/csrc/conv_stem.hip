@@ -202,6 +202,143 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_resident_kernel(const StemPa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem weight gradient, same staging: dw[co][kr*32 + px*4 + ch] = sum over output pixels of dy[.][co] * window[.][k].
+// A workgroup (8 waves) owns the WHOLE 64 x 224 filter gradient (kernel rows 0..6; row 7 of the arena layout is written as
+// zeros) for a range of tiles: wave = (16-channel fragment of co) x (16-element half of a kernel row's 32 k), 7 accumulator
+// tiles = 28 VGPRs.  A tile is two output rows = 32*MF pixels = MF reduction steps; both operands are read transposed
+// (ds_read_b64_tr_b16, the reduction index is the pixel): the window operand straight from the linear copy of the 9 image
+// rows (a pixel's window is 16 B further than its neighbour's: rows of the transposed read overlap, no bank conflicts), dy
+// from [pixel][64] rows with the 32 B-block swizzle of conv_wgrad.hip.  Per lane 2*MF + 2 read addresses, constants of the
+// whole kernel; kernel row, half, buffer and step are immediate offsets.  Slabs [workgroup][64][256] + slab_reduce_kernel
+// (which clears the entries of window pixel 7, as for the implicit-GEMM form).
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_read_pair_off(unsigned a0, unsigned a1) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int MF>
+__global__ __launch_bounds__(512, 2) void stem7x7s2_wgrad_resident_kernel(const StemWgradParams p, const int ntiles) {
+  constexpr int OW = MF * 16, W = 2 * OW, PITCH = (W + 8) * 8;
+  constexpr int A_ROWS = 9;
+  constexpr int X_BYTES = (A_ROWS * PITCH + 1023) / 1024 * 1024;
+  constexpr int XINST = X_BYTES / 1024;
+  constexpr int TPX = 2 * OW;                    // pixels per tile
+  constexpr int Y_BYTES = TPX * 128;
+  constexpr int YINST = Y_BYTES / 1024;
+  constexpr int YBASE = 2 * X_BYTES;
+  static_assert(YBASE + 2 * Y_BYTES <= 160 * 1024 && (MF - 1) * 4096 < 65536 && X_BYTES + 6 * PITCH < 65536, "LDS map / offsets");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[YBASE + 2 * Y_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cf = wave & 3, kh = wave >> 2;       // channel fragment of co, 16-element half of a kernel row
+  const bf16_t* zero = (const bf16_t*)icamd_zero_page;
+  const unsigned lds_base = (unsigned)(uintptr_t)LPTR(smem);
+  const int OH = p.OH, H = p.H;
+  const int tiles_per_image = OH >> 1;
+
+  // ---- staging (8 waves): x as in the forward kernel; dy rows keep their 32 B blocks at block ^ key(row mod 16)
+  auto stage = [&](int tile, int buf) {
+    const int n = tile / tiles_per_image, oh0 = (tile - n * tiles_per_image) * 2;
+    const int ih0 = 2 * oh0 - 3;
+    const bf16_t* xb = p.x + ((long long)n * H + ih0) * (PITCH / 2);
+#pragma unroll
+    for (int j = 0; j < (XINST + 7) / 8; ++j) {
+      const int q = j * 8 + wave;
+      if (q < XINST) {
+        const int byte = q * 1024 + lane * 16;
+        const int row = byte / PITCH;
+        const int ih = ih0 + row;
+        const bf16_t* src = (row < A_ROWS && (unsigned)ih < (unsigned)H) ? xb + (byte >> 1) : zero;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * X_BYTES + q * 1024), 16, 0, 0);
+      }
+    }
+    const bf16_t* yb = p.dy + (((long long)n * OH + oh0) * OW) * 64;     // two output rows: TPX contiguous pixels
+#pragma unroll
+    for (int j = 0; j < (YINST + 7) / 8; ++j) {
+      const int q = j * 8 + wave;
+      if (q < YINST) {
+        const int row = q * 8 + (lane >> 3);      // pixel of the tile
+        const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+        const int chunk = ((((lane & 7) >> 1) ^ key) << 1) | (lane & 1);
+        __builtin_amdgcn_global_load_lds(GPTR(yb + row * 64 + chunk * 8), LPTR(smem + YBASE + buf * Y_BYTES + q * 1024), 16, 0,
+                                         0);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) stage(tile, 0);
+
+  // ---- read roles (ds_read_b64_tr_b16: lane -> reduction row 8g + q (+4), 8 B at 8*pq of a 32 B block)
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  unsigned xa[MF][2], ya[2][2];   // dy: [buffer][row select] (its buffers lie beyond the 16-bit immediate)
+#pragma unroll
+  for (int st = 0; st < MF; ++st)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int pxl = st * 32 + 8 * g + q + 4 * s2;        // pixel of the tile
+      const int orow = pxl >= OW ? 1 : 0, ow = pxl - orow * OW;
+      xa[st][s2] = lds_base + (unsigned)(2 * orow * PITCH + ow * 16 + kh * 32 + 8 * pq);
+    }
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int row = 8 * g + q + 4 * s2;
+    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    ya[0][s2] = lds_base + (unsigned)(YBASE + row * 128 + ((cf ^ key) << 5) + 8 * pq);
+    ya[1][s2] = ya[0][s2] + (unsigned)Y_BYTES;
+  }
+
+  f32x4 acc[7];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto do_tile = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    static_for<0, MF>([&](auto stc) {
+      constexpr int st = decltype(stc)::value;
+      const bf16x8 yf = tr_read_pair_off<st * 4096>(ya[BUF][0], ya[BUF][1]);
+      bf16x8 xf[7];
+      static_for<0, 7>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        xf[r] = tr_read_pair_off<BUF * X_BYTES + r * PITCH>(xa[st][0], xa[st][1]);
+      });
+      static_for<0, 7>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        // reads return in issue order: kernel row r may start once at most 2 * (6 - r) reads are outstanding
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[r]) : "n"(2 * (6 - r)) : "memory");
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[r], yf, acc[r], 0, 0, 0);
+      });
+    });
+  };
+
+  const int step = gridDim.x;
+  for (; tile < ntiles; tile += 2 * step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // this tile landed for every wave; the other buffers are free again
+    if (tile + step < ntiles) stage(tile + step, 1);
+    do_tile(std::integral_constant<int, 0>{});
+    if (tile + step >= ntiles) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + 2 * step < ntiles) stage(tile + 2 * step, 0);
+    do_tile(std::integral_constant<int, 1>{});
+  }
+
+  // acc[r]: rows = k elements kh*16 + 4*(lane>>4) .. +3 of kernel row r, column = output channel cf*16 + (lane & 15)
+  float* slab = p.slab + (long long)blockIdx.x * 64 * 256;
+  const int co = cf * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 7; ++r) *(f32x4*)(slab + co * 256 + r * 32 + kh * 16 + 4 * (lane >> 4)) = acc[r];
+  *(f32x4*)(slab + co * 256 + 7 * 32 + kh * 16 + 4 * (lane >> 4)) = f32x4{0.f, 0.f, 0.f, 0.f};   // kernel row 7 of the layout
+}
+
 int mode() {
   static const int m = [] { const char* e = getenv("ICAMD_STEM_RESIDENT"); return e ? atoi(e) : 1; }();
   return m;
@@ -223,7 +360,37 @@ int launch(const StemParams& p, hipStream_t stream) {
   return icamd_launch_status();
 }
 
+template <int MF>
+int launch_wgrad(const StemWgradParams& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((stem7x7s2_wgrad_resident_kernel<MF>), dim3((unsigned)grid), dim3(512), 0, stream, p,
+                     p.N * (p.OH / 2));
+  return icamd_launch_status();
+}
+
 }  // namespace
+
+// one workgroup (and one slab) per CU, at most one per tile
+int icamd_stem_wgrad_resident_splits(int N, int H) {
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int ntiles = N * (H / 4);
+  return ntiles < cus ? ntiles : cus;
+}
+
+int icamd_stem_wgrad_resident_launch(StemWgradParams& p, int S, hipStream_t stream) {
+  if (!icamd_stem_resident_wanted(p.N, p.H, p.W, 64)) return ICAMD_ERR_UNSUPPORTED;
+  p.OH = p.H / 2; p.OW = p.W / 2;
+  switch (p.OW / 16) {
+    case 4: return launch_wgrad<4>(p, S, stream);
+    case 5: return launch_wgrad<5>(p, S, stream);
+    case 6: return launch_wgrad<6>(p, S, stream);
+    case 7: return launch_wgrad<7>(p, S, stream);
+    default: return launch_wgrad<8>(p, S, stream);
+  }
+}
 
 // 64 output channels, square-ish maps whose output width is 64..128 in steps of 16 and whose output height is even
 bool icamd_stem_resident_wanted(int N, int H, int W, int Cout) {

@@ -102,7 +102,15 @@ struct StemParams {
   float* stats;      // optional [ceil(M/128)][2][64]
   int N, H, W, OH, OW;
 };
+struct StemWgradParams {
+  const bf16_t* x;   // [N][H][W+8][4]
+  const bf16_t* dy;  // [N][OH][OW][64]
+  float* slab;       // [S][64][256]
+  int N, H, W, OH, OW;
+};
 bool icamd_stem_resident_wanted(int N, int H, int W, int Cout);
+int icamd_stem_wgrad_resident_splits(int N, int H);
+int icamd_stem_wgrad_resident_launch(StemWgradParams& p, int S, hipStream_t stream);
 int icamd_stem_resident_launch(StemParams& p, hipStream_t stream);
 
 // Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
