@@ -32,6 +32,8 @@ constexpr int BK = 64;
 // EPI 0: out = [relu](acc (+bias)(+addend)); optional statistics of the rounded outputs (BatchNorm forward).
 // EPI 2: EPI 0 with every optional operand compiled OUT (no bias, addend, ReLU, GELU; statistics still optional): the plain
 //        training forward and the plain data gradient, i.e. most launches of a ResNet step, run ~1/10 of the epilogue code.
+// EPI 3: EPI 2 plus a full-size addend (optionally gated by 1-bit ReLU masks) of a stride-1 problem, read COALESCED through
+//        wave-private LDS patches: the residual data gradients of the bottleneck blocks (16 launches of a ResNet-50 step).
 // EPI 1: data-gradient with the next BatchNorm-backward fused in: g = (acc + addend) * [ReLU mask], out = g, and the
 //        partial rows hold sum(g) and sum(g * xhat), xhat from the BN input `bnb_y` (BatchNorm backward, pass 1).
 // KMODE 3: the ResNet stem (7x7 stride 2 pad 3 on the [N][H][W+8][4] layout of icamd_pack_input_rgb4): the reduction is
@@ -272,7 +274,9 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
     for (int i = 0; i < 4; ++i) {
       moff[i] = 0;   // rows past M read pixel 0 (valid memory); their results are never stored
       const int m = m0 + wm * 64 + i * 16 + fr;
-      if (has_addend && m < p.M) {
+      if constexpr (EPI == 3) {   // stride-1, full-size addend: the output pixel index IS m
+        if (m < p.M) moff[i] = m * p.Cout;
+      } else if (has_addend && m < p.M) {
         const unsigned int n = fdiv((unsigned)m, p.divPQ);
         const unsigned int rem = m - n * (p.P * p.Q);
         const unsigned int pp = fdiv(rem, p.divQ);
@@ -297,16 +301,46 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         else abw[i] = *(const unsigned int*)bp;
       }
     }
+    if constexpr (EPI == 3) {
+      // Coalesced addend: in the MFMA layout a lane's 4 channels are 8 B and a wave-load touches 16 rows x 32 B; here the
+      // wave reads its 64 rows x 128 B as 16 B per lane (8 rows x 128 B per instruction), parks them in a wave-private
+      // 8 KB patch of the (now idle) stage buffer and picks its fragments back in the MFMA layout.
+      static_assert(EPI != 3 || BN == 128, "EPI 3 is instantiated for 128-channel tiles");
+      unsigned char* patch = smem + wave * 8192;
+      const int cw0 = n0 + wn * 64;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const int row = h * 8 + (lane >> 3), chunk = lane & 7;
+        const int m = m0 + wm * 64 + row;
+        const int mc = m < p.M ? m : 0;
+        const u32x4 v = *(const u32x4*)(p.addend + (long long)mc * p.Cout + cw0 + chunk * 8);
+        *(u32x4*)(patch + row * 128 + ((chunk ^ (row & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const u32x2 a = *(const u32x2*)(patch + row * 128 + ((((2 * j + (fq >> 1)) ^ (row & 7)) & 7) << 4) + ((fq & 1) << 3));
+          const unsigned int ab = (unsigned int)(abw[i] >> (8 * (j * 2 + (fq >> 1)) + 4 * (fq & 1))) & 0xfu;
+          acc[j][i][0] += (ab & 1u) ? bf16_lo(a[0]) : 0.f;
+          acc[j][i][1] += (ab & 2u) ? bf16_hi(a[0]) : 0.f;
+          acc[j][i][2] += (ab & 4u) ? bf16_lo(a[1]) : 0.f;
+          acc[j][i][3] += (ab & 8u) ? bf16_hi(a[1]) : 0.f;
+        }
+      }
+      __syncthreads();   // every wave is done with its patch before the output tile overwrites the buffer
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int cl = wn * (BN / 2) + j * 16 + 4 * fq;      // tile-local channel of this lane's 4 values
       const int cg = n0 + cl;
       const int cgc = cg < p.Cout ? cg : 0;                 // clamped: loads stay in bounds, values unused
       f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (EPI != 2 && p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
+      if (EPI < 2 && p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
       u32x2 av[4];
       unsigned int ab[4] = {0xffu, 0xffu, 0xffu, 0xffu};
-      if (has_addend) {
+      if (EPI != 3 && has_addend) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) av[i] = *(const u32x2*)(p.addend + moff[i] + cgc);
         // addend is a ReLU layer's output gradient: bit = [that output > 0]; this lane's nibble within the row word
@@ -316,14 +350,14 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = acc[j][i] + b4;
-        if (has_addend) {
+        if (EPI != 3 && has_addend) {
           const u32x2 a = av[i];
           v[0] += (ab[i] & 1u) ? bf16_lo(a[0]) : 0.f;
           v[1] += (ab[i] & 2u) ? bf16_hi(a[0]) : 0.f;
           v[2] += (ab[i] & 4u) ? bf16_lo(a[1]) : 0.f;
           v[3] += (ab[i] & 8u) ? bf16_hi(a[1]) : 0.f;
         }
-        if (EPI != 2 && p.relu) {   // inference epilogue (BatchNorm folded into filters + bias): NaN passes through like torch.relu
+        if (EPI < 2 && p.relu) {   // inference epilogue (BatchNorm folded into filters + bias): NaN passes through like torch.relu
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
         }
@@ -391,12 +425,12 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
           s2[e] += gg[e] * ((yy[e] - bmu[e]) * bis[e]);
         }
       } else {
-        if constexpr (EPI != 2) {
+        if constexpr (EPI < 2) {
           if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + roff[ps]));
           if (p.gelu_inplace) o = gelu8(o);
         }
         *(u32x4*)(p.out + roff[ps]) = o;
-        if constexpr (EPI != 2) {
+        if constexpr (EPI < 2) {
           if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + roff[ps]) = gelu8(o);
         }
         if (p.stats != nullptr) {
@@ -476,6 +510,11 @@ int icamd_igemm_launch(IgemmParams& p, hipStream_t stream) {
   const bool plain = p.bias == nullptr && p.addend == nullptr && !p.relu && p.gelu_out == nullptr && !p.gelu_inplace &&
                      p.gelu_z == nullptr;
   static const bool lean_on = [] { const char* e = getenv("ICAMD_IGEMM_LEAN"); return !(e && atoi(e) == 0); }();
+  const bool addend_only = p.bias == nullptr && p.addend != nullptr && !p.addend_sub2 && !p.relu && p.gelu_out == nullptr &&
+                           !p.gelu_inplace && p.gelu_z == nullptr && p.ostr == 1 && p.ooff_h == 0 && p.ooff_w == 0 &&
+                           p.P == p.OH && p.Q == p.OW && p.stats == nullptr;
+  static const bool epi3_on = [] { const char* e = getenv("ICAMD_IGEMM_LEAN"); return !(e && atoi(e) == 2); }();
+  if (lean_on && epi3_on && addend_only && bn == 128 && p.Cout % 128 == 0 && !cin8 && !tail) return launch<128, 0, 3>(p, stream);
   if (lean_on && plain && !cin8 && !tail) return bn == 64 ? launch<64, 0, 2>(p, stream) : launch<128, 0, 2>(p, stream);
   if (bn == 64) return cin8 ? launch<64, 1, 0>(p, stream) : (tail ? launch<64, 2, 0>(p, stream) : launch<64, 0, 0>(p, stream));
   return cin8 ? launch<128, 1, 0>(p, stream) : (tail ? launch<128, 2, 0>(p, stream) : launch<128, 0, 0>(p, stream));
