@@ -252,12 +252,12 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
   if (d->Cout % 8 != 0 || d->Cin % 8 != 0) return ICAMD_ERR_UNSUPPORTED;
   if ((long long)d->N * d->IH * d->IW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
   const int st = d->stride;
-  // (with an addend the persistent kernel pays one exposed memory latency per 32- or 64-row tile at two workgroups per CU:
-  // measured in-model, data gradients 4.27 -> 4.59 ms; those launches stay on conv_igemm unless ICAMD_PW_RESIDENT=2)
-  static const bool pw_addend = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e && atoi(e) >= 2; }();
+  // (ICAMD_PW_RESIDENT=5: the residual / even-grid addend launches stay on conv_igemm -- the A/B switch for the
+  // LDS-DMA-staged addend of conv1x1_resident.hip)
+  static const bool pw_addend = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return !(e && atoi(e) == 5); }();
   if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && f == nullptr && gelu_z == nullptr &&
       (addend == nullptr || pw_addend) && !(addend_bits != nullptr && addend_sub2) &&
-      icamd_pw_resident_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {
+      icamd_pw_resident_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout, addend != nullptr)) {
     PwResidentParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.addend = (const bf16_t*)addend;

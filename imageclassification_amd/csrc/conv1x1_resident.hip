@@ -14,7 +14,12 @@
 //   * the four waves split the channels (WN = 4: the workgroup covers 64*NF channels, every wave reads the same activation
 //     fragments) or, for 64-channel outputs, the rows (WN = 1);
 //   * wave-private epilogue: MFMA layout -> [addend] -> bf16 -> two 16-row LDS patches -> 16 B row stores; BatchNorm partial
-//     sums stay in registers across tiles and leave as one partial row per workgroup.
+//     sums stay in registers across tiles and leave as one partial row per workgroup;
+//   * the addend of the residual data gradients (full-size, optionally gated by 1-bit ReLU masks, or the even-grid form of
+//     icamd_conv2d_dgrad_sub2) is brought by LDS-DMA into a wave-private patch at the start of the tile -- whole rows, 16 B
+//     per lane, no registers, zero page for rows that have none -- and read back in the MFMA layout after the MFMAs.
+//     (Loaded in the MFMA layout into registers instead, 8 B per lane, the same launches were SLOWER than conv_igemm:
+//     data gradients 4.27 -> 4.59 ms per step; staged this way 4.22 -> 3.88 ms.)
 #include "common.h"
 #include "icamd_internal.h"
 #include <cstdlib>
@@ -54,7 +59,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int NINST = A_BYTES / 1024;         // LDS-DMA instructions per tile
   constexpr int IPW = NINST / 4;                // per wave
   static_assert(NINST % 4 == 0 && (NF == 2 || NF == 4) && KS >= 2 && KS <= 16, "configuration");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE];
+  constexpr int P_WAVE = ADD ? MF * 16 * EROW : 0;   // ADD: this wave's [MF*16 rows][CW] addend patch (LDS-DMA target)
+  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,36 +131,45 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     for (int j = 0; j < NF; ++j)
 #pragma unroll
       for (int i = 0; i < MF; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // addend fragments (MFMA layout: this lane's 4 channels of row i*16 + fr): ALL loads are issued before the tile's
-    // MFMAs, so their latency hides under them (the ADD form carries no statistics: those registers pay for these)
+    // ADD: the tile's addend sub-tile of THIS wave goes to its LDS patch by LDS-DMA (16 B per lane, whole rows: coalesced;
+    // no registers; lands under the MFMAs below; rows past M and, for the even-grid form, odd pixels come from the zero
+    // page, so no mask is needed for them); the 1-bit masks of the wave's 16*NF channels are one word per row.
     const int mw = tm0 + wm * MF * 16;
-    u32x2 av[ADD ? MF : 1][ADD ? NF : 1];
-    unsigned int ab[ADD ? MF : 1][ADD ? NF : 1];
+    unsigned long long abw[ADD ? MF : 1];
     bool has_add = false;
+    unsigned char* const sP = smem + 2 * A_BYTES + 4 * E_WAVE + wave * P_WAVE;
     if constexpr (ADD) {
-      has_add = p.addend != nullptr;        // uniform
-      if (has_add) {
+      has_add = true;
+      constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;      // lanes per patch row, rows per instruction
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-          const int m = mw + i * 16 + fr;
-          const int mc = m < p.M ? m : 0;
-          long long off = (long long)mc * p.N;
-          bool ok = true;
+      for (int q = 0; q < P_WAVE / 1024; ++q) {
+        const int row = q * RPIA + lane / LPRA, pos = lane % LPRA;
+        const int chunk = pos ^ (row & (LPRA - 1));
+        const int m = mw + row;
+        const bf16_t* src = zero;
+        if (m < p.M) {
           if (p.sub2_h > 0) {     // addend on the even pixel grid only (icamd_conv2d_dgrad_sub2)
-            const unsigned int n = fdiv((unsigned)mc, p.divHW);
-            const unsigned int rem = mc - n * (p.sub2_h * p.sub2_w);
+            const unsigned int n = fdiv((unsigned)m, p.divHW);
+            const unsigned int rem = m - n * (p.sub2_h * p.sub2_w);
             const unsigned int hh = fdiv(rem, p.divW);
             const unsigned int ww = rem - hh * p.sub2_w;
-            ok = ((hh | ww) & 1u) == 0u;
-            off = (((long long)n * ((p.sub2_h + 1) >> 1) + (hh >> 1)) * ((p.sub2_w + 1) >> 1) + (ww >> 1)) * p.N;
+            if (((hh | ww) & 1u) == 0u)
+              src = p.addend + ((((long long)n * ((p.sub2_h + 1) >> 1) + (hh >> 1)) * ((p.sub2_w + 1) >> 1) + (ww >> 1)) * p.N +
+                                n0 + chunk * 8);
+          } else {
+            src = p.addend + ((long long)m * p.N + n0 + chunk * 8);
           }
+        }
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sP + q * 1024), 16, 0, 0);
+      }
 #pragma unroll
-          for (int j = 0; j < NF; ++j) {
-            const long long e = off + n0 + j * 16 + 4 * fq;
-            av[i][j] = *(const u32x2*)(p.addend + e);
-            ab[i][j] = ok ? 0xfu : 0u;
-            if (p.addend_bits != nullptr) ab[i][j] = ((unsigned int)p.addend_bits[e >> 3] >> (4 * (fq & 1))) & 0xfu;
-          }
+      for (int i = 0; i < MF; ++i) {
+        abw[i] = ~0ull;
+        if (p.addend_bits != nullptr) {
+          const int m = mw + i * 16 + fr;
+          const unsigned char* bp = p.addend_bits + (((long long)(m < p.M ? m : 0) * p.N + n0) >> 3);
+          if constexpr (NF == 4) abw[i] = *(const unsigned long long*)bp;
+          else abw[i] = *(const unsigned int*)bp;
         }
       }
     }
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     });
 
     // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
+    if constexpr (ADD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's addend patch (and bit words) landed
     static_for<0, (MF + 1) / 2>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
 #pragma unroll
@@ -184,8 +201,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
             f32x4 v = acc[j][i];
             if constexpr (ADD) {
               if (has_add) {
-                const u32x2 a = av[i][j];
-                const unsigned int bb = ab[i][j];
+                constexpr int LPRA = EROW / 16;
+                const int prow = i * 16 + fr, aslot = j * 4 + fq;
+                const u32x2 a = *(const u32x2*)(sP + prow * EROW + ((((aslot >> 1) ^ prow) & (LPRA - 1)) << 4) + ((aslot & 1) << 3));
+                const unsigned int bb = (unsigned int)(abw[i] >> (8 * (j * 2 + (fq >> 1)) + 4 * (fq & 1))) & 0xfu;
                 v[0] += (bb & 1u) ? bf16_lo(a[0]) : 0.f;
                 v[1] += (bb & 2u) ? bf16_hi(a[0]) : 0.f;
                 v[2] += (bb & 4u) ? bf16_lo(a[1]) : 0.f;
@@ -233,13 +252,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   for (; m0 < m_end; m0 += 2 * TM) {
     // this tile has landed for every wave and every wave is done with the other buffer; behind the tile's loads in the
     // queue: the previous tile's STORES row stores (full tiles always issue all of them; a ragged tile is a range's last)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ADD ? 0 : STORES) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (m0 + TM < m_end) stage(m0 + TM, 1);
     tile(std::integral_constant<int, 0>{}, m0);
     if (m0 + TM >= m_end) break;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ADD ? 0 : STORES) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (m0 + 2 * TM < m_end) stage(m0 + 2 * TM, 0);
@@ -296,18 +315,21 @@ bool pick(int N, int K, Config* c) {
 
 template <int KS, int NF, int MF, int WN>
 int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
-  if (p.addend != nullptr)
-    hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-  else
+  if (p.addend != nullptr) {
+    // (K = 256 with 32-channel waves: activation buffers + addend patches exceed the 80 KB of two workgroups per CU)
+    if constexpr (KS == 8 && NF == 2) return ICAMD_ERR_UNSUPPORTED;
+    else hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  } else
     hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   return icamd_launch_status();
 }
 
 }  // namespace
 
-bool icamd_pw_resident_wanted(long long M, int N, int K) {
+bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend) {
   Config c;
   if (mode() == 0 || M <= 0 || M >= (1ll << 30) || !pick(N, K, &c)) return false;
+  if (with_addend && c.ks == 8 && c.nf == 2) return false;
   // persistent workgroups need rows to amortise the filter load: at least ~8 tiles per workgroup at 512 workgroups
   const int tm = (4 / c.wn) * c.mf * 16;
   const int ntn = N / (c.wn * c.nf * 16);

@@ -91,7 +91,7 @@ struct PwResidentParams {
   FastDiv divHW, divW;   // filled by the launcher
   int rows_per_split, ntiles_n;   // filled by the launcher
 };
-bool icamd_pw_resident_wanted(long long M, int N, int K);
+bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend = false);
 int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream);
 
 // ResNet stem forward with the filter resident in registers (conv_stem.hip)
