@@ -2,6 +2,7 @@
 // Wave = 64 lanes everywhere; bf16 values travel as raw 16-bit patterns (unsigned short).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #define ICAMD_OK 0
@@ -88,6 +89,45 @@ __device__ __forceinline__ u32x4 gelu_bwd8(const u32x4 da, const u32x4 z) {
   for (int e = 0; e < 4; ++e)
     o[e] = pack_bf16x2(bf16_lo(da[e]) * gelu_grad_f(bf16_lo(z[e])), bf16_hi(da[e]) * gelu_grad_f(bf16_hi(z[e])));
   return o;
+}
+
+// ---- helpers of the persistent "operand resident in registers" kernels (conv3x3_halo.hip, conv1x1_resident.hip,
+// conv_stem.hip, conv_wgrad.hip) ----
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- the index is usable as an asm immediate
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// LDS reads through inline asm with an IMMEDIATE offset.  hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of C++
+// (and builtin) LDS loads while an LDS-DMA is in flight, because it cannot tell the buffers apart; the asm form is invisible
+// to it and its completion is waited for by hand (counted s_waitcnt lgkmcnt naming the destination as an in/out operand).
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128_off(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_read_pair_off(unsigned a0, unsigned a1) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// CUs of the current device (persistent grids are sized from it); 256 if the query fails
+static inline int icamd_num_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+    return cus;
+  }();
+  return n;
 }
 
 static inline int icamd_launch_status() {

@@ -23,25 +23,8 @@
 #include "common.h"
 #include "icamd_internal.h"
 #include <cstdlib>
-#include <type_traits>
 
 namespace {
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read128_off(unsigned addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
 
 // KS: k-steps of 32 (K = 32*KS); NF: 16-channel fragments per wave; MF: 16-row fragments per wave; WN: waves across the
 // channels (4 / WN across the rows); ADD: addend epilogue compiled in.
@@ -55,7 +38,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int EROW = CW * 2;                  // bytes per row of the epilogue patch (128 or 64)
   constexpr int E_WAVE = 2 * 16 * EROW;         // two 16-row patches per wave
   constexpr int NV = KS < 4 ? KS : 4;           // address variants (k-step bits that the row swizzle touches)
-  constexpr int RPI = 1024 / ROWB > 0 ? 1024 / ROWB : 1;   // rows per LDS-DMA instruction
   constexpr int NINST = A_BYTES / 1024;         // LDS-DMA instructions per tile
   constexpr int IPW = NINST / 4;                // per wave
   static_assert(NINST % 4 == 0 && (NF == 2 || NF == 4) && KS >= 2 && KS <= 16, "configuration");
@@ -79,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   // bank span, so their key is (row >> 1) & 7; wider rows all start on bank 0 and use row & 15.
   auto sw = [](int row) { return ROWB == 128 ? (row >> 1) & 7 : row & 15; };
 
-  // ---- staging: instruction j of wave w is instruction q = j*4 + w of the tile: 1 KiB = RPI rows (or part of one row)
+  // ---- staging: instruction j of wave w is instruction q = j*4 + w of the tile: 1 KiB = 1024 / ROWB rows (or part of one)
   auto stage = [&](int m0, int buf) {
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
@@ -346,7 +328,8 @@ int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
   const int tm = (4 / c.wn) * c.mf * 16;
   p.ntiles_n = p.N / (c.wn * c.nf * 16);
   // two workgroups per CU; the statistics table has ceil(M/128) rows, one per split at most
-  int S = (512 + p.ntiles_n - 1) / p.ntiles_n;
+  const int wgs = 2 * icamd_num_cus();
+  int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
   const int cap_tiles = (p.M + tm - 1) / tm, cap_rows = (p.M + 127) / 128;
   if (S > cap_tiles) S = cap_tiles;
   if (p.stats != nullptr && S > cap_rows) S = cap_rows;

@@ -555,19 +555,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_resident_kernel(const Halo
   }
 }
 
-int resident_cus() {
-  static const int n = [] {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
-    return cus;
-  }();
-  return n;
-}
-
 int launch_resident_c64(const Halo3x3Params& p, hipStream_t stream) {
   const int ntiles = (p.M + 127) / 128;
-  const int slots = 2 * resident_cus();                // two workgroups per CU
+  const int slots = 2 * icamd_num_cus();                // two workgroups per CU
   const int grid = ntiles < slots ? ntiles : slots;
   if (p.bias != nullptr || p.relu)
     hipLaunchKernelGGL((conv3x3_c64_resident_kernel<true>), dim3((unsigned)grid), dim3(256), 0, stream, p, ntiles);
@@ -661,5 +651,5 @@ int icamd_halo3x3_launch(Halo3x3Params& p, hipStream_t stream) {
   }
   if (la <= 5) return launch_halo<64, 1, 2, 5, 6, 32, 3>(p, stream);
   if (la <= 6) return launch_halo<64, 1, 2, 6, 6, 32, 3>(p, stream);
-  return launch_halo<64, 1, 2, 8, 6, 32, 3>(p, stream);
+  return launch_halo<64, 1, 2, 8, 6, 32, 2>(p, stream);   // 32 + 24 = 56 KB: two workgroups per CU
 }

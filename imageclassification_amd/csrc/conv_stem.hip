@@ -18,25 +18,8 @@
 #include "common.h"
 #include "icamd_internal.h"
 #include <cstdlib>
-#include <type_traits>
 
 namespace {
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read128_off(unsigned addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
 
 // MF = OW / 16 fragments per output row; PITCH = (W + 8) * 8 bytes per image row.
 template <int MF>
@@ -212,15 +195,6 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_resident_kernel(const StemPa
 // from [pixel][64] rows with the 32 B-block swizzle of conv_wgrad.hip.  Per lane 2*MF + 2 read addresses, constants of the
 // whole kernel; kernel row, half, buffer and step are immediate offsets.  Slabs [workgroup][64][256] + slab_reduce_kernel
 // (which clears the entries of window pixel 7, as for the implicit-GEMM form).
-template <int OFF>
-__device__ __forceinline__ bf16x8 tr_read_pair_off(unsigned a0, unsigned a1) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit field");
-  bf16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
-  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
 template <int MF>
 __global__ __launch_bounds__(512, 2) void stem7x7s2_wgrad_resident_kernel(const StemWgradParams p, const int ntiles) {
   constexpr int OW = MF * 16, W = 2 * OW, PITCH = (W + 8) * 8;
@@ -347,12 +321,7 @@ int mode() {
 template <int MF>
 int launch(const StemParams& p, hipStream_t stream) {
   const int ntiles = p.N * (p.OH / 2);
-  int cus = 256, dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
-  int grid = 2 * cus;
+  int grid = 2 * icamd_num_cus();
   const int nrows = (p.N * p.OH * p.OW + 127) / 128;
   if (grid > ntiles) grid = ntiles;
   if (grid > nrows) grid = nrows;
@@ -371,12 +340,7 @@ int launch_wgrad(const StemWgradParams& p, int grid, hipStream_t stream) {
 
 // one workgroup (and one slab) per CU, at most one per tile
 int icamd_stem_wgrad_resident_splits(int N, int H) {
-  int cus = 256, dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
-  const int ntiles = N * (H / 4);
+  const int ntiles = N * (H / 4), cus = icamd_num_cus();
   return ntiles < cus ? ntiles : cus;
 }
 

@@ -528,14 +528,6 @@ int pick_side(int n) {
 //   * per 32-pixel step and wave: 22 transposed reads, 18 MFMAs (v_mfma_f32_16x16x32_bf16).
 // The ResNet-50 3x3 layers at batch 256 all become 256 workgroups x 3136 pixels (1 / 4 / 16 / 64 filter blocks x
 // 256 / 64 / 16 / 4 pixel splits), 37.7 MB of fp32 slabs, reduced in fixed order by slab_reduce_kernel.
-template <int OFF>
-__device__ __forceinline__ bf16x8 tr_read_pair_off(unsigned a0, unsigned a1) {
-  bf16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
-  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
 constexpr int HW_CH = 128;                 // pixels per chunk
 constexpr int HW_XS = 256;                 // staged x rows per buffer: HW_CH + 2W + 2 <= 256
 constexpr int HW_XB = HW_XS * 128, HW_YB = HW_CH * 128;
