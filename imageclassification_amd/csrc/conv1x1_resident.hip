@@ -288,8 +288,10 @@ bool pick(int N, int K, Config* c) {
   if (K == 64 && N == 64) { *c = {2, 4, 1, 1}; return true; }
   if (K == 128 && N % 256 == 0) { *c = {4, 4, 4, 4}; return true; }
   if (K == 256 && N % 256 == 0) { *c = {8, 4, 2, 4}; return true; }
-  // (K = 256, N = 64 -- four waves of 16 rows x 64 channels, the whole filter in each -- was built and measured: it ties
-  // conv_igemm in isolation (102 us, 256 -> 64 at 56x56) and loses in-model, so it is not instantiated)
+  // K = 256, N = 64: 2 x 2 waves of 32 rows x 32 channels (64 filter VGPRs): data gradient of 64 -> 256 at 56x56 97 -> 90 us,
+  // forward of 256 -> 64 unchanged.  (Four waves of 16 rows x 64 channels with the whole filter in each tied conv_igemm in
+  // isolation and lost in-model.)
+  if (K == 256 && N == 64) { *c = {8, 2, 2, 2}; return true; }
   if (K == 256 && N % 128 == 0) { *c = {8, 2, 4, 4}; return true; }
   if (K == 512 && N % 128 == 0) { *c = {16, 2, 2, 4}; return true; }
   return false;
@@ -299,7 +301,7 @@ template <int KS, int NF, int MF, int WN>
 int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
   if (p.addend != nullptr) {
     // (K = 256 with 32-channel waves: activation buffers + addend patches exceed the 80 KB of two workgroups per CU)
-    if constexpr (KS == 8 && NF == 2) return ICAMD_ERR_UNSUPPORTED;
+    if constexpr (KS == 8 && NF == 2 && WN == 4) return ICAMD_ERR_UNSUPPORTED;
     else hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   } else
     hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
@@ -311,7 +313,7 @@ int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
 bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend) {
   Config c;
   if (mode() == 0 || M <= 0 || M >= (1ll << 30) || !pick(N, K, &c)) return false;
-  if (with_addend && c.ks == 8 && c.nf == 2) return false;
+  if (with_addend && c.ks == 8 && c.nf == 2 && c.wn == 4) return false;
   // persistent workgroups need rows to amortise the filter load: at least ~8 tiles per workgroup at 512 workgroups
   const int tm = (4 / c.wn) * c.mf * 16;
   const int ntn = N / (c.wn * c.nf * 16);
@@ -346,6 +348,7 @@ int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
   if (c.ks == 2 && c.wn == 4) return launch<2, 4, 4, 4>(p, grid, stream);
   if (c.ks == 2) return launch<2, 4, 1, 1>(p, grid, stream);
   if (c.ks == 4) return launch<4, 4, 4, 4>(p, grid, stream);
+  if (c.ks == 8 && c.wn == 2) return launch<8, 2, 2, 2>(p, grid, stream);
   if (c.ks == 8 && c.nf == 4) return launch<8, 4, 2, 4>(p, grid, stream);
   if (c.ks == 8) return launch<8, 2, 4, 4>(p, grid, stream);
   return launch<16, 2, 2, 4>(p, grid, stream);

@@ -288,7 +288,10 @@ bool icamd_gemm_nt_wanted(long long M, int N, int K) {
   // Measured on MI355X, round 2 (tools/one_layer.py under rocprofv3): at K = 256 / 512 (ResNet-50's deep 1x1 layers) the
   // 128x128 implicit-GEMM kernel is 5-15 % FASTER (256->1024 at 14x14: 52.6 vs 58.2 us; 2048->512 data gradient at 7x7:
   // 40.2 vs 44.3 us); this kernel wins from ViT's K = 768 up.
-  return K >= 768 && N >= 256 && ((M + TM - 1) / TM) * ((N + 255) / 256) >= 256;
+  // (K >= 2048: the 7x7 layers of ResNet-50 -- 2048 -> 512 forward 52.9 -> 40.0 us, 512 -> 2048 data gradient 52.0 -> 39.1 us --
+  // have only 98 tile pairs but sixty-four ring stages each)
+  const long long pairs = ((M + TM - 1) / TM) * ((N + 255) / 256);
+  return K >= 768 && N >= 256 && (pairs >= 256 || (K >= 2048 && pairs >= 96));
 }
 
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream) {
