@@ -19,9 +19,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -137,6 +134,26 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N rank processes ourselves, the way the reference's
+    README starts multi-GPU training (`torchrun --nproc_per_node=N train.py`, /root/reference/README.md:21; rendezvous
+    variables read as in utils.py:339-375).  The ranks are FRESH child processes of torch.distributed.run, started before this
+    process has imported torch or touched the GPU; this process never does either: it relays the children's output (rank 0
+    prints the JSON line) and exits with the launcher's return code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"no WORLD_SIZE in the environment: launching {n} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +168,17 @@ def main():
     ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--pmc-file", default="r02_pmc_traffic.json", help="PMC traffic summary under profiles/")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches resident in HBM (SURVEY 8d: K >= 8)")
+    ap.add_argument("--transport", default=None, choices=["torch", "rccl"],
+                    help="gradient transport at N > 1: torch.distributed's RCCL process group (default) or the library's own "
+                         "RCCL communicator (icamd_allreduce_bucket_launch)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    global torch, dist
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,7 +221,7 @@ def main():
         net = ConvNeXt(args.arch, C, device=str(device), drop_path_rate=0.05, seed=88)   # reference --drop_path default
     else:
         net = ResNet(args.arch, C, device=str(device), seed=88)
-    model = DistributedDataParallel(net) if world > 1 else net
+    model = DistributedDataParallel(net, transport=args.transport) if world > 1 else net
     # ranks in the communicator that carries the gradients, asked of the live RCCL communicator (ncclCommCount) at N > 1
     ranks_seen = model.reducer.ranks_seen() if world > 1 else 1
     if world > 1:
@@ -359,6 +386,7 @@ def main():
                "train_stats": {k: round(v, 5) for k, v in stats.items()}}
         print(json.dumps(out))
     if world > 1:
+        model.shutdown()            # destroys the library's own communicator when one was made
         dist.destroy_process_group()
 
 

@@ -139,7 +139,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
 
-int icamd_abi_version(void) { return 2; }
+int icamd_abi_version(void) { return 3; }
 
 int icamd_prof_enable(int on) { g_prof_on = on != 0; return ICAMD_OK; }
 int icamd_prof_classes(void) { return PC_COUNT; }
@@ -922,7 +922,7 @@ int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_
   ProfScope _prof(PC_LOSS, stream);
   if (loss_out == nullptr || finite_out == nullptr || acc_f64 == nullptr || B <= 0) return ICAMD_ERR_BAD_ARG;
   if (pred != nullptr && target == nullptr) return ICAMD_ERR_BAD_ARG;
-  if (loss_rows == nullptr && pred == nullptr) return ICAMD_ERR_BAD_ARG;
+  if (loss_rows == nullptr && pred == nullptr && !(respect_skip & 4)) return ICAMD_ERR_BAD_ARG;
   return icamd_step_metrics_launch(loss_rows, pred, (const long long*)target, B, C, loss_out, finite_out, acc_f64, counts,
                                    loss_log, log_slot, log_stride, respect_skip, (hipStream_t)stream);
 }

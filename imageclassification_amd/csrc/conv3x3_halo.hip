@@ -598,7 +598,7 @@ bool icamd_halo3x3_wanted(int N, int H, int W, int C, int Cout) {
   if (resident_c64_ok(W, C, Cout)) return true;
   if (halo_mode() == 1 && C < 256) return false;
   if ((long long)N * H * W >= (1ll << 30)) return false;
-  if (2 * W + 3 + 128 > 4 * 12 * 8) return false;       // widest staged tile: 384 slots
+  if (2 * W + 3 + 128 > 4 * 8 * 8) return false;        // the 128-pixel tile (always a candidate) stages <= 256 slots (LA <= 8)
   return true;
 }
 
@@ -618,6 +618,7 @@ int icamd_halo3x3_launch(Halo3x3Params& p, hipStream_t stream) {
     long long best = -1;
     for (int cand : {256, 224, 128}) {
       if (cand == 224 && bn != 128) continue;
+      if ((cand + 2 * p.W + 3 + 31) / 32 > (cand == 128 ? 8 : 12)) continue;   // tile + halo must fit the staged slots
       const long long tiles = (long long)((p.M + cand - 1) / cand) * p.ntiles_n;
       const long long cost = ((tiles + 511) / 512) * cand + (cand == 128 ? 16 : 0);   // small tiles re-read the filter more
       if (best < 0 || cost < best) { best = cost; bm = cand; }

@@ -113,9 +113,11 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
     s_finite = *finite_out;   // metrics-only call: honour the flag the loss call of this step left behind
   }
   __syncthreads();
-  if (respect_skip && !s_finite) return;
+  if (respect_skip & 2) return;                    // flag call: loss, flag and log only; accumulation is a later call's
+  if ((respect_skip & 1) && !s_finite) return;
+  const bool add_loss = have_loss || (respect_skip & 4);   // bit 2: the deferred accumulation of an earlier flag call
   if (pred == nullptr) {
-    if (threadIdx.x == 0 && have_loss) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
+    if (threadIdx.x == 0 && add_loss) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
     return;
   }
   int correct = 0;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (have_loss) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
+    if (add_loss) { acc_f64[0] += (double)*loss_out; acc_f64[1] += 1.0; }
     acc_f64[2] += (double)((float)cred[0] / (float)B);
     if (loss_log != nullptr && log_stride > 0) loss_log[log_stride + log_slot] = (float)cred[0] / (float)B;
     acc_f64[3] += (double)cred[0];
@@ -206,9 +208,11 @@ __device__ __forceinline__ void bias_corrections(const AdamArgs& a, const int* _
   }
 }
 // the skip path of every optimizer kernel: one thread counts the dropped step (nobody reads the counter in this launch)
-__device__ __forceinline__ bool step_skipped(const int* __restrict__ finite_flag, int* __restrict__ skipped) {
+// `flags` bit 1 (ICAMD_OPT_NO_SKIP_COUNT): this launch covers one range of a step that several launches apply (one per
+// gradient bucket); only the launch without the bit counts the dropped step.
+__device__ __forceinline__ bool step_skipped(const int* __restrict__ finite_flag, int* __restrict__ skipped, int flags) {
   if (finite_flag == nullptr || *finite_flag != 0) return false;
-  if (skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1;
+  if (skipped != nullptr && !(flags & 2) && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1;
   return true;
 }
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
                                                         bf16_t* __restrict__ shadow, long long n4, AdamArgs a,
                                                         const float* __restrict__ clip, const int* __restrict__ finite_flag,
                                                         int* __restrict__ skipped, int zero_grad) {
-  if (step_skipped(finite_flag, skipped)) return;
+  if (step_skipped(finite_flag, skipped, zero_grad)) return;
   float bc1, bc2_sqrt;
   bias_corrections(a, skipped, bc1, bc2_sqrt);
   const float gs = a.gscale * (clip != nullptr ? clip[1] : 1.f);
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
     ((f32x4*)p)[i] = pv;
     ((f32x4*)m)[i] = mv;
     ((f32x4*)v)[i] = vv;
-    if (zero_grad) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (zero_grad & 1) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ema != nullptr) {
       f32x4 ev = ((f32x4*)ema)[i];
 #pragma unroll
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, f
                                                         bf16_t* __restrict__ shadow, long long n4, AdamArgs a,
                                                         const float* __restrict__ clip, const int* __restrict__ finite_flag,
                                                         int* __restrict__ skipped, int zero_grad) {
-  if (step_skipped(finite_flag, skipped)) return;
+  if (step_skipped(finite_flag, skipped, zero_grad)) return;
   float bc1, bc2_sqrt;
   bias_corrections(a, skipped, bc1, bc2_sqrt);
   const float gs = a.gscale * (clip != nullptr ? clip[1] : 1.f);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, f
     ((f32x4*)p)[i] = pv;
     ((f32x4*)m)[i] = mv;
     if (KIND == 1) ((f32x4*)v)[i] = vv;
-    if (zero_grad) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (zero_grad & 1) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ema != nullptr) {
       f32x4 ev = ((f32x4*)ema)[i];
 #pragma unroll

@@ -81,6 +81,14 @@ def default_comm():
     return _default_comm
 
 
+def destroy_default_comm():
+    """ncclCommDestroy of the process-wide communicator (call before dist.destroy_process_group())."""
+    global _default_comm
+    if _default_comm is not None:
+        _default_comm.destroy()
+        _default_comm = None
+
+
 def make_buckets(n_elems, first_bucket_elems, bucket_elems, align=64, last_bucket_elems=0):
     """[(lo, hi)] covering [0, n_elems) from the END backwards; boundaries aligned to `align` elements.
 
@@ -107,10 +115,12 @@ def make_buckets(n_elems, first_bucket_elems, bucket_elems, align=64, last_bucke
 class GradReducer:
     """Bucketed, overlapped all-reduce of a flat gradient tensor.
 
-    Transports: "rccl" -- the library's RCCL call site (`icamd_allreduce_bucket_launch` on the side stream; default for
-    device tensors when the process group's backend is nccl, i.e. RCCL); "torch" -- torch.distributed (gloo for the CPU /
-    shared-GPU world_size-2 tests).  ICAMD_DDP_TRANSPORT overrides.  `force=True` runs the collectives at world size 1 too
-    (the single-GPU test of the real transport and of the stream / event chain)."""
+    Transports: "torch" (default) -- torch.distributed's process group: RCCL over xGMI when the backend is nccl, gloo for the
+    CPU / shared-GPU world_size-2 tests; "rccl" -- the library's own RCCL call site (`icamd_allreduce_bucket_launch` on the
+    side stream through a second communicator), opt-in with transport="rccl" / ICAMD_DDP_TRANSPORT=rccl / `bench.py
+    --transport rccl` until a run with two or more GPUs has validated it (tests/test_rccl_gpu.py::test_two_gpu_* is gated on
+    torch.cuda.device_count() >= 2).  `force=True` runs the collectives at world size 1 too (the single-GPU test of the real
+    transport and of the stream / event chain)."""
 
     def __init__(self, flat_grad, first_bucket_mb=1.0, bucket_mb=25.0, process_group=None, last_bucket_mb=4.0,
                  transport=None, force=False, comm=None):
@@ -122,8 +132,7 @@ class GradReducer:
         if transport is None:
             transport = os.environ.get("ICAMD_DDP_TRANSPORT", "")
         if not transport:
-            backend = dist.get_backend(process_group) if dist.is_initialized() else ("nccl" if self.on_gpu else "gloo")
-            transport = "rccl" if (self.on_gpu and backend == "nccl") else "torch"
+            transport = "torch"
         if transport not in ("rccl", "torch"):
             raise ValueError(f"unknown gradient transport {transport!r}")
         self.transport = transport
@@ -137,11 +146,18 @@ class GradReducer:
         self._next = 0
         self._works = []
         self.launched = []   # bucket indices in launch order (tests)
+        # called as cb(lo, hi, bucket_index) with the side stream current, right behind that bucket's all-reduce: the
+        # per-bucket optimizer launch (engine.train_one_epoch sets it for the steps that can use it).  Device tensors only.
+        self.bucket_callback = None
+        self.callbacks = []  # bucket indices whose callback ran, in order (tests)
+        self._flag_reduced = False
 
     def reset(self):
         self._next = 0
         self._works = []
         self.launched = []
+        self.callbacks = []
+        self._flag_reduced = False
 
     def grads_ready_from(self, lo, wait_events=()):
         """Backward reports that every gradient at offset >= lo is final once the current stream and `wait_events`
@@ -167,8 +183,37 @@ class GradReducer:
             else:
                 with torch.cuda.stream(self.comm_stream):
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            if self.bucket_callback is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    self.bucket_callback(lo, hi, bi)
+                self.callbacks.append(bi)
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_flag(self, finite_flag):
+        """MIN-reduce the finite-loss flag (int32 [1]) over the ranks NOW, on the side stream: the flag depends on the
+        forward only, so it is final on every rank before the first gradient bucket goes out; everything enqueued on the side
+        stream afterwards (the per-bucket optimizer launches) sees the reduced value.  The main stream sees it after
+        finish() / wait()."""
+        if not self.active:
+            return
+        self._flag_reduced = True
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())          # the flag is written by the main stream's metrics kernel
+            self.comm_stream.wait_event(ev)
+            if self.comm is not None:
+                self.comm.all_reduce(finite_flag, RED_MIN, self.comm_stream.cuda_stream)
+            else:
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_reduce(finite_flag, op=dist.ReduceOp.MIN, group=self.group)
+        else:
+            dist.all_reduce(finite_flag, op=dist.ReduceOp.MIN, group=self.group)
+
+    def wait(self):
+        """The main stream waits for everything the side stream holds (no buckets are flushed)."""
+        if self.active and self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     @property
     def active(self):
@@ -190,6 +235,9 @@ class GradReducer:
         if not self.active:
             return
         self.grads_ready_from(0)
+        if self._flag_reduced:
+            finite_flag = None           # reduce_flag() already did it for this step
+            self._flag_reduced = False
         if self.on_gpu:
             if finite_flag is not None:
                 ev = torch.cuda.Event()
@@ -238,6 +286,16 @@ class DistributedDataParallel:
     def sync_buffers(self):
         if self.reducer.active:
             self._broadcast(self.module.buffer_arena)
+
+    def shutdown(self):
+        """Release the library's own communicator (if this wrapper's reducer made one)."""
+        if self.reducer.comm is not None:
+            torch.cuda.synchronize()
+            if self.reducer.comm is _default_comm:
+                destroy_default_comm()
+            else:
+                self.reducer.comm.destroy()
+            self.reducer.comm = None
 
     def train(self, mode=True):
         self.module.train(mode)

@@ -20,6 +20,7 @@ import time
 import torch
 
 from . import hip, utils
+from .mixup import sample_params
 
 LOG_RING = 4096
 
@@ -100,6 +101,16 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
     hook = net.grad_ready_hook
     steps_run = 0
     grad_norm = None
+    # data-parallel steps: the finite-loss flag is MIN-reduced over the ranks right after the loss (it depends on the forward
+    # only), the metrics are accumulated from the REDUCED flag at the end of the step, and -- when nothing needs the whole
+    # gradient first (no clipping, no accumulation window) -- the optimizer runs as one launch per gradient bucket on the
+    # reducer's side stream, each behind that bucket's all-reduce (reference: DDP hooks + optimizer.step(), train.py:218-222,
+    # engine.py:74).  ICAMD_BUCKET_OPTIM=0 keeps the single launch behind the last bucket.
+    dp = reducer is not None and reducer.active and reducer.on_gpu
+    bucket_optim = (dp and update_freq == 1 and not (use_amp and max_norm is not None) and hasattr(optimizer, "step_range")
+                    and os.environ.get("ICAMD_BUCKET_OPTIM", "1") != "0")
+    if reducer is not None:
+        reducer.bucket_callback = None
 
     for data_iter_step, (samples, targets) in enumerate(data_loader):
         step = data_iter_step // update_freq
@@ -119,12 +130,16 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         B = samples.shape[0]
         s = hip.stream_ptr()
 
-        mix = mixup_fn.sample(samples.shape) if mixup_fn is not None else None
+        # the reference calls mixup_fn(samples, targets) (engine.py:44) on whatever train.py:176-185 built; here the mixing
+        # runs inside the packing / loss kernels, so only the object's configuration is used to draw (mode, lambda, box)
+        mix = None
+        if mixup_fn is not None:
+            mix = mixup_fn.sample(samples.shape) if hasattr(mixup_fn, "sample") else sample_params(mixup_fn, samples.shape)
         ws = net.pack(samples, mix)
         logits = net.forward_packed(ws)
 
         if mixup_fn is not None:
-            smoothing, lam = mixup_fn.label_smoothing, mix[1]
+            smoothing, lam = float(mixup_fn.label_smoothing), mix[1]
             flipped = targets.flip(0).contiguous()
         else:
             smoothing, lam, flipped = _criterion_smoothing(criterion), 1.0, None
@@ -134,17 +149,38 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
                                          None if flipped is None else flipped.data_ptr(), float(lam), float(smoothing),
                                          1.0 / (B * update_freq), ws["loss_rows"].data_ptr(), ws["pred"].data_ptr(),
                                          ws["dlogits"].data_ptr(), s), "softmax_xent")
-        hip.check(lib.icamd_step_metrics(ws["loss_rows"].data_ptr(), ws["pred"].data_ptr() if want_pred else None,
-                                         targets.data_ptr(), B, num_classes, st.loss.data_ptr(), st.finite.data_ptr(),
-                                         st.acc.data_ptr(), st.counts.data_ptr(), st.log.data_ptr(), slot, LOG_RING, 1, s),
-                  "step_metrics")
-
+        pred_ptr = ws["pred"].data_ptr() if want_pred else None
         is_update = (data_iter_step + 1) % update_freq == 0
+        if dp:
+            # flag call (loss, flag, log slot; nothing accumulated) -> MIN over the ranks on the side stream
+            hip.check(lib.icamd_step_metrics(ws["loss_rows"].data_ptr(), None, targets.data_ptr(), B, num_classes,
+                                             st.loss.data_ptr(), st.finite.data_ptr(), st.acc.data_ptr(), st.counts.data_ptr(),
+                                             st.log.data_ptr(), slot, LOG_RING, 2, s), "step_metrics (flag)")
+            reducer.reduce_flag(st.finite)
+            if bucket_optim and is_update:
+                optimizer.begin_step()
+                reducer.bucket_callback = lambda lo, hi, _bi: optimizer.step_range(
+                    lo, hi, model_ema=model_ema, grad_scale=grad_scale, finite_flag=st.finite)
+        else:
+            hip.check(lib.icamd_step_metrics(ws["loss_rows"].data_ptr(), pred_ptr, targets.data_ptr(), B, num_classes,
+                                             st.loss.data_ptr(), st.finite.data_ptr(), st.acc.data_ptr(), st.counts.data_ptr(),
+                                             st.log.data_ptr(), slot, LOG_RING, 1, s), "step_metrics")
+
         net.grad_ready_hook = hook if is_update else None   # reduce once per optimizer step (sum of micro-steps)
         net.backward_packed(ws, accumulate=(data_iter_step % update_freq) != 0)
         net.grad_ready_hook = hook
-        if is_update and reducer is not None:
-            reducer.finish(st.finite)   # gradients summed over ranks; the finite flag becomes the MIN over ranks
+        if dp:
+            if is_update:
+                reducer.finish()        # gradients summed over ranks (and, per bucket, applied); main stream waits
+                reducer.bucket_callback = None
+            else:
+                reducer.wait()          # the reduced flag
+            # every rank counts (or drops) the same steps: accumulate from the REDUCED flag
+            hip.check(lib.icamd_step_metrics(None, pred_ptr, targets.data_ptr(), B, num_classes, st.loss.data_ptr(),
+                                             st.finite.data_ptr(), st.acc.data_ptr(), st.counts.data_ptr(), st.log.data_ptr(),
+                                             slot, LOG_RING, 1 | 4, s), "step_metrics (accumulate)")
+        elif is_update and reducer is not None:
+            reducer.finish(st.finite)   # CPU tensors / inactive reducer
         if update_freq > 1:
             # reference engine.py:56-59: a non-finite micro-batch zero_grad()s (dropping what the window had accumulated
             # so far) and is skipped; decided on the device, no host sync
@@ -154,7 +190,10 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             if use_amp:
                 # reference utils.py:438-442: clip_grad_norm_ when clip_grad is given, else only measure the norm
                 grad_norm = optimizer.measure_grad_norm(max_norm if clip else None, grad_scale=grad_scale)
-            optimizer.step(model_ema=model_ema, grad_scale=grad_scale, use_clip=clip, finite_flag=st.finite)
+            if bucket_optim:
+                optimizer.finish_step(model_ema, st.finite)     # every range was applied behind its bucket's all-reduce
+            else:
+                optimizer.step(model_ema=model_ema, grad_scale=grad_scale, use_clip=clip, finite_flag=st.finite)
 
         if mixup_fn is not None and not cheap_mixup_acc:
             # reference engine.py:89-97: accuracy of the un-mixed images through the (already updated) model,

@@ -64,7 +64,11 @@ class GpuImagePipeline:
         self.std = (ctypes.c_float * 3)(*std)
         self.device = torch.device(device)
         self._ws = None
-        self._pinned = None
+        # two pinned staging buffers (images + descriptor table), alternated per batch; an event recorded behind each
+        # upload guards the buffer's reuse, so nothing on the batch path waits for the training kernels queued on the stream
+        self._pinned = [None, None]
+        self._copied = [None, None]
+        self._turn = 0
 
     def _kmax(self, crop):
         support = 2.0 if self.filter == 1 else 1.0
@@ -76,9 +80,15 @@ class GpuImagePipeline:
             params = [draw_train_params(S, self.color_jitter, self.reprob) if self.train else None for _ in images]
         descs = (hip.ImageDesc * B)()
         total = sum(int(im.shape[0]) * int(im.shape[1]) * 3 for im in images)
-        if self._pinned is None or self._pinned.numel() < total:
-            self._pinned = torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory()
-        host = self._pinned.numpy()
+        total_al = (total + 255) // 256 * 256
+        dsize = ctypes.sizeof(descs)
+        k = self._turn
+        self._turn = 1 - k
+        if self._copied[k] is not None:
+            self._copied[k].synchronize()        # the upload that last read this buffer (two batches ago) has finished
+        if self._pinned[k] is None or self._pinned[k].numel() < total_al + dsize:
+            self._pinned[k] = torch.empty(max(total_al + dsize, 1 << 20), dtype=torch.uint8).pin_memory()
+        host = self._pinned[k].numpy()
         off, max_crop, kmax = 0, 1, 3
         for i, (im, pr) in enumerate(zip(images, params)):
             if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
@@ -106,10 +116,13 @@ class GpuImagePipeline:
             max_crop = max(max_crop, d.crop_h)
             kmax = max(kmax, self._kmax(d.crop_h), self._kmax(d.crop_w))
             off += n
-        src = torch.empty(total, dtype=torch.uint8, device=self.device)
-        src.copy_(self._pinned[:total], non_blocking=True)
-        dbytes = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
-        ddev = dbytes.to(self.device)
+        host[total_al:total_al + dsize] = np.frombuffer(bytes(descs), dtype=np.uint8)
+        staged = torch.empty(total_al + dsize, dtype=torch.uint8, device=self.device)
+        staged.copy_(self._pinned[k][:total_al + dsize], non_blocking=True)      # one async upload: images + descriptors
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._copied[k] = ev
+        src, ddev = staged[:total], staged[total_al:]
         need = self.lib.icamd_image_pipeline_workspace_bytes(B, max_crop, S, S, kmax)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)

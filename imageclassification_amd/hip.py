@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libicamd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERRORS = {1: "ICAMD_ERR_BAD_ARG", 2: "ICAMD_ERR_UNSUPPORTED", 3: "ICAMD_ERR_WORKSPACE", 4: "ICAMD_ERR_LAUNCH"}
 
 

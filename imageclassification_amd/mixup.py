@@ -55,32 +55,53 @@ class Mixup:
         self.mixup_enabled = True
 
     def sample(self, shape):
-        assert shape[0] % 2 == 0, "Batch size should be even when using this"
-        lam, use_cutmix = 1.0, False
-        if self.mixup_enabled and np.random.rand() < self.mix_prob:
-            if self.mixup_alpha > 0.0 and self.cutmix_alpha > 0.0:
-                use_cutmix = np.random.rand() < self.switch_prob
-                alpha = self.cutmix_alpha if use_cutmix else self.mixup_alpha
-                lam = float(np.random.beta(alpha, alpha))
-            elif self.mixup_alpha > 0.0:
-                lam = float(np.random.beta(self.mixup_alpha, self.mixup_alpha))
-            elif self.cutmix_alpha > 0.0:
-                use_cutmix = True
-                lam = float(np.random.beta(self.cutmix_alpha, self.cutmix_alpha))
-            else:
-                raise AssertionError("One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true.")
-        if lam == 1.0:
-            return 0, 1.0, (0, 0, 0, 0)
-        if use_cutmix:
-            if self.cutmix_minmax is not None:
-                box = rand_bbox_minmax(shape, self.cutmix_minmax)
-            else:
-                box = rand_bbox(shape, lam)
-            if self.correct_lam or self.cutmix_minmax is not None:
-                area = (box[1] - box[0]) * (box[3] - box[2])
-                lam = 1.0 - area / float(shape[-2] * shape[-1])
-            return 2, lam, box
-        return 1, lam, (0, 0, 0, 0)
+        return sample_params(self, shape)
+
+
+_MIXUP_FIELDS = ("mixup_alpha", "cutmix_alpha", "mix_prob", "switch_prob", "label_smoothing", "num_classes")
+
+
+def sample_params(cfg, shape):
+    """Per-batch (mode, lam, box) drawn from ANY object that carries timm.data.Mixup's public fields -- this package's Mixup
+    or the object the reference builds at train.py:176-185 and passes as `mixup_fn` (engine.py:44): `mixup_alpha`,
+    `cutmix_alpha`, `cutmix_minmax`, `mix_prob`, `switch_prob`, `correct_lam`, `mixup_enabled`, `mode`.  The fields are read
+    at every call (timm's `mixup_off_epoch` flips `mixup_enabled` on the live object).  Only mode "batch" (the reference
+    default, train.py:79) is built: "pair" / "elem" draw per-sample parameters the fused packing kernel does not take."""
+    missing = [f for f in _MIXUP_FIELDS if not hasattr(cfg, f)]
+    if missing:
+        raise TypeError(f"mixup_fn of type {type(cfg).__name__} lacks timm.data.Mixup's field(s) {missing}: the MI355X "
+                        "engine draws the mixing parameters itself from the object's configuration")
+    mode = getattr(cfg, "mode", "batch")
+    if mode != "batch":
+        raise ValueError(f"mixup mode {mode!r} is not built for the MI355X path (only timm's 'batch' mode, the reference "
+                         "default train.py:79)")
+    assert shape[0] % 2 == 0, "Batch size should be even when using this"
+    minmax = getattr(cfg, "cutmix_minmax", None)
+    lam, use_cutmix = 1.0, False
+    if getattr(cfg, "mixup_enabled", True) and np.random.rand() < cfg.mix_prob:
+        if cfg.mixup_alpha > 0.0 and cfg.cutmix_alpha > 0.0:
+            use_cutmix = np.random.rand() < cfg.switch_prob
+            alpha = cfg.cutmix_alpha if use_cutmix else cfg.mixup_alpha
+            lam = float(np.random.beta(alpha, alpha))
+        elif cfg.mixup_alpha > 0.0:
+            lam = float(np.random.beta(cfg.mixup_alpha, cfg.mixup_alpha))
+        elif cfg.cutmix_alpha > 0.0:
+            use_cutmix = True
+            lam = float(np.random.beta(cfg.cutmix_alpha, cfg.cutmix_alpha))
+        else:
+            raise AssertionError("One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true.")
+    if lam == 1.0:
+        return 0, 1.0, (0, 0, 0, 0)
+    if use_cutmix:
+        if minmax is not None:
+            box = rand_bbox_minmax(shape, minmax)
+        else:
+            box = rand_bbox(shape, lam)
+        if getattr(cfg, "correct_lam", True) or minmax is not None:
+            area = (box[1] - box[0]) * (box[3] - box[2])
+            lam = 1.0 - area / float(shape[-2] * shape[-1])
+        return 2, lam, box
+    return 1, lam, (0, 0, 0, 0)
 
 
 class _Criterion:

@@ -47,25 +47,48 @@ class FusedAdamW:
                                            self.norm_clip.data_ptr(), hip.stream_ptr()), "grad_norm")
         return self.norm_clip[0]
 
-    def step(self, model_ema=None, grad_scale=1.0, use_clip=False, finite_flag=None, zero_grad=False):
+    def _launch(self, lo, hi, model_ema, grad_scale, use_clip, finite_flag, flags):
+        """The fused kernel over arena elements [lo, hi) on the current stream."""
         g = self.param_groups[0]
         m = self.model
-        self.step_count += 1
         ema_ptr = None
         decay = 0.0
         if model_ema is not None:
-            ema_ptr = model_ema.param_arena.data_ptr()
+            ema_ptr = model_ema.param_arena.data_ptr() + 4 * lo
             decay = model_ema.decay
-        hip.check(self.lib.icamd_adamw_ema(m.param_arena.data_ptr(), m.grad_arena.data_ptr(), self.exp_avg.data_ptr(),
-                                           self.exp_avg_sq.data_ptr(), ema_ptr, m.shadow.data_ptr(), m.n_params,
+        hip.check(self.lib.icamd_adamw_ema(m.param_arena.data_ptr() + 4 * lo, m.grad_arena.data_ptr() + 4 * lo,
+                                           self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, ema_ptr,
+                                           m.shadow.data_ptr() + 2 * lo, hi - lo,
                                            float(g["lr"]), float(g["weight_decay"]), float(g["betas"][0]),
                                            float(g["betas"][1]), float(g["eps"]), self.step_count, float(grad_scale),
                                            float(decay), self.norm_clip.data_ptr() if use_clip else None,
                                            None if finite_flag is None else finite_flag.data_ptr(),
-                                           self.skipped.data_ptr(), int(zero_grad), hip.stream_ptr()), "adamw_ema")
-        m.refresh_transposed()
+                                           self.skipped.data_ptr(), int(flags), hip.stream_ptr()), "adamw_ema")
+
+    def step(self, model_ema=None, grad_scale=1.0, use_clip=False, finite_flag=None, zero_grad=False):
+        self.step_count += 1
+        self._launch(0, self.model.n_params, model_ema, grad_scale, use_clip, finite_flag, int(bool(zero_grad)))
+        self.finish_step(model_ema, finite_flag)
+
+    # -- one optimizer step as several launches, one per gradient bucket (ddp.GradReducer.bucket_callback) ------------
+    def begin_step(self):
+        """Count the step once; the range launches that follow belong to it."""
+        self.step_count += 1
+        self._ranges_in_step = 0
+
+    def step_range(self, lo, hi, model_ema=None, grad_scale=1.0, finite_flag=None):
+        """Apply the step to arena elements [lo, hi) (multiples of 4) on the CURRENT stream -- the reducer's side stream,
+        right behind that bucket's all-reduce.  Element for element the same arithmetic as step(): the result is
+        bit-identical to the single launch.  Only the first range of a step counts a dropped step."""
+        flags = 0 if self._ranges_in_step == 0 else 2      # ICAMD_OPT_NO_SKIP_COUNT
+        self._ranges_in_step += 1
+        self._launch(lo, hi, model_ema, grad_scale, False, finite_flag, flags)
+
+    def finish_step(self, model_ema=None, finite_flag=None):
+        """What follows the parameter update once every range is applied: transposed filters, EMA of the buffers."""
+        self.model.refresh_transposed()
         if model_ema is not None:
-            model_ema.after_fused_update(m, finite_flag)
+            model_ema.after_fused_update(self.model, finite_flag)
 
     @property
     def steps_taken(self):
@@ -119,28 +142,24 @@ class FusedOptimizer(FusedAdamW):
         if kind not in (OPT_ADAMW, OPT_ADAM):
             self.exp_avg_sq = None   # only the Adam family keeps second moments
 
-    def step(self, model_ema=None, grad_scale=1.0, use_clip=False, finite_flag=None, zero_grad=False):
+    def _launch(self, lo, hi, model_ema, grad_scale, use_clip, finite_flag, flags):
         g = self.param_groups[0]
         m = self.model
-        self.step_count += 1
         if self.kind in (OPT_SGD_MOMENTUM, OPT_SGD_NESTEROV):
             b1, b2, eps = g["momentum"], 0.0, 0.0
         else:
             b1, b2, eps = g["betas"][0], g["betas"][1], g.get("eps", 0.0)
         ema_ptr, decay = None, 0.0
         if model_ema is not None:
-            ema_ptr, decay = model_ema.param_arena.data_ptr(), model_ema.decay
-        hip.check(self.lib.icamd_optim_ema(self.kind, m.param_arena.data_ptr(), m.grad_arena.data_ptr(),
-                                           self.exp_avg.data_ptr(),
-                                           None if self.exp_avg_sq is None else self.exp_avg_sq.data_ptr(), ema_ptr,
-                                           m.shadow.data_ptr(), m.n_params, float(g["lr"]), float(g["weight_decay"]),
+            ema_ptr, decay = model_ema.param_arena.data_ptr() + 4 * lo, model_ema.decay
+        hip.check(self.lib.icamd_optim_ema(self.kind, m.param_arena.data_ptr() + 4 * lo, m.grad_arena.data_ptr() + 4 * lo,
+                                           self.exp_avg.data_ptr() + 4 * lo,
+                                           None if self.exp_avg_sq is None else self.exp_avg_sq.data_ptr() + 4 * lo, ema_ptr,
+                                           m.shadow.data_ptr() + 2 * lo, hi - lo, float(g["lr"]), float(g["weight_decay"]),
                                            float(b1), float(b2), float(eps), self.step_count, float(grad_scale),
                                            float(decay), self.norm_clip.data_ptr() if use_clip else None,
                                            None if finite_flag is None else finite_flag.data_ptr(),
-                                           self.skipped.data_ptr(), int(zero_grad), hip.stream_ptr()), "optim_ema")
-        m.refresh_transposed()
-        if model_ema is not None:
-            model_ema.after_fused_update(m, finite_flag)
+                                           self.skipped.data_ptr(), int(flags), hip.stream_ptr()), "optim_ema")
 
     def state_dict(self):
         sd = super().state_dict() if self.exp_avg_sq is not None else {

@@ -298,7 +298,11 @@ int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* 
  * acc_f64[0]+=loss, [1]+=1, [2]+=correct/B, [3]+=correct, [4]+=B ; counts int32[3][C] = TP, FP, FN.
  * loss_rows == NULL: metrics-only call (uses the finite flag already in *finite_out; acc[0], acc[1] untouched);
  * pred == NULL: loss-only call.  loss_log[log_slot] <- loss; loss_log[log_stride + log_slot] <- correct/B
- * (log_stride > 0). */
+ * (log_stride > 0).
+ * respect_skip is a bit set: 1 = skip the accumulation when the flag is down; 2 = FLAG CALL: write loss_out, finite_out
+ * and the log slot, accumulate nothing (data-parallel steps MIN-reduce the flag over the ranks between this call and the
+ * accumulating one, so that every rank counts or drops the same steps); 4 = on a metrics-only call (loss_rows == NULL)
+ * also add *loss_out to acc[0] and 1 to acc[1] -- the accumulation a flag call left out (pred may then be NULL). */
 int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_t* target, int B, int C,
                        float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
                        int log_slot, int log_stride, int respect_skip, void* stream);
@@ -314,7 +318,12 @@ int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm
  * -> `continue` before optimizer.step(), engine.py:56-59).
  * `step` >= 1 counts the steps ATTEMPTED (this one included); skipped_steps (device int32, may be NULL) counts the ones
  * the device dropped: the kernel adds 1 to it when it skips, and the bias correction uses t = step - *skipped_steps, the
- * number of steps really taken -- what torch.optim's `step` state would hold in the reference. */
+ * number of steps really taken -- what torch.optim's `step` state would hold in the reference.
+ * zero_grad is a bit set: ICAMD_OPT_ZERO_GRAD (1) clears the gradient behind the update; ICAMD_OPT_NO_SKIP_COUNT (2) marks
+ * a launch that applies ONE RANGE of a step several launches share (one per gradient bucket, each behind that bucket's
+ * all-reduce): p/g/m/v/ema/shadow then point at the range, and only the one launch of the step without the bit adds the
+ * dropped step to *skipped_steps (a skipped step is skipped by all of them: they read the same flag). */
+enum { ICAMD_OPT_ZERO_GRAD = 1, ICAMD_OPT_NO_SKIP_COUNT = 2 };
 int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow, long long n, float lr, float wd,
                     float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
                     const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream);

@@ -25,10 +25,22 @@ def build(arch, C):
 
 
 def main():
+    """argv: [--transport torch|rccl] arch...   env ICAMD_RANK_BACKEND: gloo (default: both ranks share GPU 0) or nccl (one GPU
+    per rank, RCCL: tests/test_rccl_gpu.py::test_two_gpu_*)."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda")
+    backend = os.environ.get("ICAMD_RANK_BACKEND", "gloo")
+    argv = sys.argv[1:]
+    transport = None
+    if argv and argv[0] == "--transport":
+        transport, argv = argv[1], argv[2:]
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     from imageclassification_amd import hip
     from imageclassification_amd.ddp import DistributedDataParallel
     from imageclassification_amd.engine import train_one_epoch
@@ -37,10 +49,12 @@ def main():
     from imageclassification_amd.utils import NativeScalerWithGradNormCount
     lib = hip.load()
     C, B = 10, 8
-    for arch in sys.argv[1:]:
+    for arch in argv:
         net, hw = build(arch, C)
-        ddp = DistributedDataParallel(net, first_bucket_mb=0.05, bucket_mb=0.5)   # many buckets on a small model
+        ddp = DistributedDataParallel(net, first_bucket_mb=0.05, bucket_mb=0.5, transport=transport)   # many buckets on a small model
         assert len(ddp.reducer.buckets) >= 3, len(ddp.reducer.buckets)
+        if transport is not None:
+            assert ddp.reducer.transport == transport and ddp.reducer.ranks_seen() == world
         g = torch.Generator().manual_seed(100 + rank)
         x = torch.randn(B, 3, hw, hw, generator=g).to(dev)
         y = torch.randint(0, C, (B,), generator=g).to(dev)
@@ -74,6 +88,7 @@ def main():
 
         # two optimizer steps through the drop-in boundary: ranks stay bit-identical
         opt = create_optimizer("adamw", 1e-3, 0.05, net)
+        ddp.reducer.reset()
         data = [(torch.randn(B, 3, hw, hw, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(2)]
         train_one_epoch(ddp, LabelSmoothingCrossEntropy(0.1), data, opt, dev, 0, NativeScalerWithGradNormCount(), None, None,
                         None, start_steps=0, lr_schedule_values=[1e-3, 1e-3], wd_schedule_values=[0.05, 0.05],
@@ -83,9 +98,28 @@ def main():
         both = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(both, mine)
         assert torch.equal(both[0], both[1]), arch
+        # the optimizer ran as one launch per bucket, each behind that bucket's all-reduce on the side stream
+        assert ddp.reducer.callbacks == ddp.reducer.launched and len(ddp.reducer.callbacks) == 2 * len(ddp.reducer.buckets)
+        assert opt.steps_taken == 2
+
+        # a non-finite loss on ONE rank: the MIN-reduced flag makes BOTH ranks drop the step and count it as dropped
+        before = net.param_arena.clone()
+        bad = data[0][0].clone()
+        if rank == 1:
+            bad[0, 0, 0, 0] = float("inf")
+        stats = train_one_epoch(ddp, LabelSmoothingCrossEntropy(0.1), [(bad, data[0][1])], opt, dev, 0,
+                                NativeScalerWithGradNormCount(), None, None, None, start_steps=0, lr_schedule_values=[1e-2],
+                                wd_schedule_values=[0.0], num_training_steps_per_epoch=1, update_freq=1, use_amp=True,
+                                num_classes=C)
+        torch.cuda.synchronize()
+        assert torch.equal(net.param_arena, before), (arch, "step not dropped on rank", rank)
+        assert opt.steps_taken == 2 and stats == {}, (opt.steps_taken, stats)    # no step counted in the meters on ANY rank
+        ddp.shutdown()
         if rank == 0:
             print(f"ddp-ok {arch} buckets={len(ddp.reducer.buckets)} grad_err={err:.2e}", flush=True)
     dist.barrier()
+    if rank == 0 and backend == "nccl":
+        print(f"rccl2-ok {transport}", flush=True)
     dist.destroy_process_group()
 
 

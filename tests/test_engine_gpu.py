@@ -172,6 +172,41 @@ def test_mixup_path_runs_second_forward_and_soft_targets():
     assert stats["loss"] > 0.5
 
 
+class _TimmStyleMixup:
+    """Stand-in for the object the reference builds (timm.data.Mixup, train.py:176-185): timm's attribute names and a
+    __call__(x, target) -- which the MI355X engine never calls (the mixing runs in the packing / loss kernels)."""
+
+    def __init__(self, mixup_alpha=1., cutmix_alpha=0., cutmix_minmax=None, prob=1.0, switch_prob=0.5, mode="batch",
+                 correct_lam=True, label_smoothing=0.1, num_classes=1000):
+        self.mixup_alpha, self.cutmix_alpha, self.cutmix_minmax = mixup_alpha, cutmix_alpha, cutmix_minmax
+        self.mix_prob, self.switch_prob, self.label_smoothing, self.num_classes = prob, switch_prob, label_smoothing, num_classes
+        self.mode, self.correct_lam, self.mixup_enabled = mode, correct_lam, True
+
+    def __call__(self, x, target):
+        raise AssertionError("the engine must not run the host-side mixing")
+
+
+def test_reference_mixup_object_is_accepted():
+    """`mixup_fn` as the reference passes it (engine.py:44): an object with timm.data.Mixup's public fields gives the very
+    step this package's Mixup gives (same numpy draws, same kernels); unsupported modes raise a clear error."""
+    from imageclassification_amd.mixup import Mixup, SoftTargetCrossEntropy
+    C, B = 10, 8
+    data = _loader(3, B, C, seed=24)
+    out = []
+    for cls in (Mixup, _TimmStyleMixup):
+        _, net, opt, _ = _setup(C, seed=3)
+        np.random.seed(3)
+        mix = cls(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)
+        stats = _train(net, opt, data, C, crit=SoftTargetCrossEntropy(), mixup_fn=mix)
+        out.append((stats, net.param_arena.clone()))
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+    _, net, opt, _ = _setup(C, seed=3)
+    with pytest.raises(ValueError, match="mode"):
+        _train(net, opt, data, C, crit=SoftTargetCrossEntropy(), mixup_fn=_TimmStyleMixup(mode="elem", num_classes=C))
+    with pytest.raises(TypeError, match="mixup_alpha"):
+        _train(net, opt, data, C, crit=SoftTargetCrossEntropy(), mixup_fn=object())
+
+
 def test_evaluate_matches_oracle_and_key_order():
     from imageclassification_amd.engine import evaluate
     C, B = 5, 12

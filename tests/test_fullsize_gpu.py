@@ -9,7 +9,10 @@ step: size-independent properties of the step instead of element-wise comparison
 * ViT-B/16 (no batch statistics): the gradient of the 256-image batch is the mean of the gradients of its two halves
   (1/B is a power of two, so the only difference is fp32 summation order) -- the identity data parallelism rests on;
 * BatchNorm in train mode: the batch statistics written by the step are those of the stored conv output (fp64 check on
-  the stem: 256 x 112 x 112 x 64 values).
+  the stem: 256 x 112 x 112 x 64 values);
+* BASELINE configs[4] at its own size -- ConvNeXt-T, batch 256, mixup / cutmix soft targets, stochastic depth, AdamW + EMA:
+  the mixed step twice is bit-identical, every dlogits row sums to zero for the soft targets, a cutmix step equals the step
+  on the explicitly pasted images, and the EMA recursion holds on the trajectory train_one_epoch produces.
 """
 import pytest
 import torch
@@ -89,3 +92,74 @@ def test_vit_base_full_batch_gradient_is_the_mean_of_its_halves():
     # twice the same step: bit-identical
     _step(net, x, y)
     assert torch.equal(net.grad_arena.double(), g_full)
+
+
+def _mixed_step(net, x, y, mix, smoothing=0.1, seed=7):
+    """One ConvNeXt step on a mixed batch: (mode, lam, box) applied inside the packing kernel, soft targets
+    lam*onehot_s(y) + (1-lam)*onehot_s(y.flip(0)) inside the loss kernel; stochastic-depth masks drawn from torch's CPU RNG."""
+    from imageclassification_amd import hip
+    lib = hip.load()
+    torch.manual_seed(seed)                      # the per-sample stochastic-depth masks of this step
+    ws = net.pack(x, mix)
+    logits = net.forward_packed(ws)
+    n = x.shape[0]
+    flipped = y.flip(0).contiguous()
+    hip.check(lib.icamd_softmax_xent(logits.data_ptr(), net.ncls_p, n, C, y.data_ptr(), flipped.data_ptr(), float(mix[1]),
+                                     smoothing, 1.0 / n, ws["loss_rows"].data_ptr(), ws["pred"].data_ptr(),
+                                     ws["dlogits"].data_ptr(), hip.stream_ptr()), "xent")
+    net.backward_packed(ws)
+    torch.cuda.synchronize()
+    return ws
+
+
+def test_convnext_tiny_config4_full_batch_properties():
+    """BASELINE configs[4] at full size: ConvNeXt-T, batch 256 x 224^2, mixup 0.8 / cutmix 1.0 / label smoothing 0.1 soft
+    targets, drop-path 0.05, AdamW + ModelEmaV3(0.9995) (reference recipe train.py:172-201, loop engine.py:44-77)."""
+    import numpy as np
+    from imageclassification_amd.convnext import ConvNeXt
+    from imageclassification_amd.ema import ModelEmaV3
+    from imageclassification_amd.engine import train_one_epoch
+    from imageclassification_amd.mixup import Mixup, SoftTargetCrossEntropy
+    from imageclassification_amd.optim_factory import create_optimizer
+    from imageclassification_amd.utils import NativeScalerWithGradNormCount
+    net = ConvNeXt("convnext_tiny", C, drop_path_rate=0.05, seed=3)
+    x, y = _data(seed=90)
+    # (1) a mixup step and a cutmix step: finite, rows of dlogits sum to zero for the soft targets, bit-reproducible
+    box = (40, 150, 64, 200)                                           # yl, yh, xl, xh
+    lam_cut = 1.0 - (box[1] - box[0]) * (box[3] - box[2]) / float(HW * HW)
+    for mix in ((1, 0.37, (0, 0, 0, 0)), (2, lam_cut, box)):
+        ws = _mixed_step(net, x, y, mix)
+        loss1, grad1, dl1 = ws["loss_rows"].clone(), net.grad_arena.clone(), ws["dlogits"].clone()
+        assert torch.isfinite(loss1).all() and torch.isfinite(grad1).all() and float(grad1.abs().max()) > 0
+        rows = dl1.float()[:, :C].double().sum(1)
+        assert float(rows.abs().max()) <= 2e-3 * float(dl1.float().abs().max()) * 8, mix
+        assert float(dl1.float()[:, C:].abs().max()) == 0.0
+        ws = _mixed_step(net, x, y, mix)
+        assert torch.equal(ws["loss_rows"], loss1) and torch.equal(ws["dlogits"], dl1) and torch.equal(net.grad_arena, grad1)
+        if mix[0] == 2:
+            # the fused cutmix equals an un-mixed step on explicitly pasted images with the same soft targets
+            pasted = x.clone()
+            pasted[:, :, box[0]:box[1], box[2]:box[3]] = x.flip(0)[:, :, box[0]:box[1], box[2]:box[3]]
+            ws = _mixed_step(net, pasted, y, (0, lam_cut, (0, 0, 0, 0)))
+            assert torch.equal(ws["loss_rows"], loss1) and torch.equal(net.grad_arena, grad1)
+    # (2) the composition through the drop-in boundary: 3 steps of train_one_epoch with mixup_fn + EMA; the EMA recursion
+    # ema <- ema + (1 - decay) * (p - ema) holds on the trajectory (parameters AND the lerp are the fused kernel's)
+    decay = 0.9995
+    ema = ModelEmaV3(net, decay=decay)
+    opt = create_optimizer("adamw", 1e-3, 5e-2, net)
+    np.random.seed(5)
+    mixer = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)
+    expect = net.param_arena.clone()
+    xc, yc = x.cpu(), y.cpu()
+    moved = 0.0
+    for i in range(3):
+        before = net.param_arena.clone()
+        st = train_one_epoch(net, SoftTargetCrossEntropy(), [(xc, yc)], opt, DEV, 0, NativeScalerWithGradNormCount(), None, ema,
+                             mixer, start_steps=i, lr_schedule_values=[1e-3] * 3, wd_schedule_values=[5e-2] * 3,
+                             num_training_steps_per_epoch=1, update_freq=1, use_amp=True, num_classes=C)
+        assert np.isfinite(st["loss"]) and 6.0 < st["loss"] < 8.0 and 0.0 <= st["class_acc"] <= 1.0
+        expect = expect + (1.0 - decay) * (net.param_arena - expect)
+        moved += float((net.param_arena - before).abs().max())
+    assert moved > 0 and opt.steps_taken == 3
+    assert torch.allclose(ema.param_arena, expect, rtol=1e-6, atol=1e-9)
+    assert float((ema.param_arena - net.param_arena).abs().max()) > 0      # the EMA lags the model: it is not a copy

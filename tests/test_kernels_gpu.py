@@ -342,6 +342,9 @@ HALO_CASES = [  # N, H, W, C, Cout: 3x3 stride 1 pad 1 layers routed to csrc/con
     (2, 13, 11, 128, 256), (1, 3, 3, 64, 64), (5, 16, 16, 64, 128),
     # 64 -> 64: the register-resident persistent kernel; > 256 tiles (workgroups loop, both LDS buffers), ragged last tile
     (24, 56, 56, 64, 64), (40, 9, 13, 64, 64), (300, 16, 16, 64, 64),
+    # widest rows: W = 62 is the last width the halo tiles can stage (128 + 2W + 3 = 255 slots; the 256-pixel tile needs all
+    # 12 x 32); W = 64 with >= 256 channels must fall back to the implicit-GEMM kernel, not fail
+    (1, 6, 62, 256, 256), (1, 5, 64, 256, 256), (2, 4, 126, 256, 64),
 ]
 
 

@@ -113,18 +113,34 @@ class _As64(torch.nn.Module):
         return self.m(x.double())
 
 
-def test_resnet50_whole_network_parity_well_conditioned():
-    """ResNet-50 (the headline network), timm's default init, batch 32 at 128x128: every BatchNorm reduces over >= 512
-    values.  The yardstick -- the oracle against its own fp64-accumulating copy, same bf16 rounding points -- is ASSERTED to
-    be small (logits <= 5e-3; over the gradient tensors mean <= 4e-2 and worst <= 6e-2: the stem's BatchNorm bias sits at
-    3.4e-2 on any two CPUs), so this test cannot degenerate into accepting anything -- an all-zero or mis-wired gradient
-    scores 1.0; the HIP path must then sit within 2x of it (floors: north_star's 1e-3 on logits / loss).  With the last BatchNorm weight of each
-    block at zero the residual branches receive an exactly-zero gradient in both implementations: asserted to be EXACTLY
-    zero on the HIP side (the branches' backward is exercised by the trajectory test below, after the first optimizer step
-    has moved those weights, and by the teacher-forced test)."""
+@pytest.mark.parametrize("gamma_last", [0.0, 0.02])
+def test_resnet50_whole_network_parity_well_conditioned(gamma_last):
+    """ResNet-50 (the headline network), batch 32 at 128x128: every BatchNorm reduces over >= 512 values.  The yardstick --
+    the oracle against its own fp64-accumulating copy, same bf16 rounding points -- is ASSERTED to be small first, so this
+    test cannot degenerate into accepting anything (an all-zero or mis-wired gradient scores 1.0, a sign error 2.0); the HIP
+    path must then sit within 2x of it (floors: north_star's 1e-3 on logits / loss).
+
+    gamma_last = 0: timm's default init, the configuration the reference really trains from.  With the last BatchNorm weight
+    of each block at zero the residual branches receive an exactly-zero gradient in both implementations (asserted EXACTLY
+    zero on the HIP side): 49 of 161 tensors are compared, yardstick logits <= 5e-3, gradients mean <= 4e-2 / worst <= 6e-2.
+
+    gamma_last = 0.02: the same network with every block's last BatchNorm weight at 0.02, so that ALL 161 gradient tensors
+    -- every bottleneck conv1 / conv2 / conv3, bn1 / bn2: every 3x3 data and weight gradient -- are non-zero and compared at
+    t = 0.  Why 0.02 and not 0.25-0.5: bf16 training differs between any two correct implementations by ReLU-mask flips
+    (a fraction f of flipped bits costs sqrt(f) in relative L2 of a gradient), and residual branches with O(1) weight
+    amplify forward differences block after block: measured on the CPU oracle alone, fp64 vs fp32 accumulation, the
+    gradients differ by a MEAN relative L2 of 0.30 at gamma 0.25 and 0.59 at gamma 0.5 (worst 0.43 / 0.79) -- a yardstick
+    that cannot tell a wrong gradient from a right one.  At 0.02 the branches do not amplify, the gradient only crosses their
+    two inner ReLU masks: yardstick mean 8.7e-2, worst 1.5e-1 (a BatchNorm bias in layer4: a sum with cancellation), asserted
+    <= 0.13 / 0.22; a dropped term, tap or stride class in any branch kernel scores >= 0.5 on its tensor."""
     import copy
     C, B, HW = 100, 32, 128
     ref, net = _timm_default_pair("resnet50", C)
+    if gamma_last:
+        for n, m in ref.named_modules():
+            if n.endswith("bn3"):
+                m.weight.data.fill_(gamma_last)
+        net.load_state_dict(ref.state_dict())
     ref64 = copy.deepcopy(ref).double()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, 3, HW, HW, generator=g)
@@ -155,12 +171,23 @@ def test_resnet50_whole_network_parity_well_conditioned():
     mean_e = sum(r[1] for r in rows) / len(rows)
     mean_n = sum(r[2] for r in rows) / len(rows)
     worst = max(rows, key=lambda r: r[1])
-    print(f"resnet50 B={B} {HW}x{HW}: logits err {err_logits:.2e} (self-noise {noise_logits:.2e}); loss {hip_loss:.6f} vs "
-          f"{float(loss):.6f}; {len(rows)} gradient tensors: mean err {mean_e:.2e} (self-noise {mean_n:.2e}), worst "
-          f"{worst[0]} {worst[1]:.2e} (its self-noise {worst[2]:.2e}); {zero_branch} zero-gradient branch tensors exact")
+    print(f"resnet50 B={B} {HW}x{HW} gamma_last={gamma_last}: logits err {err_logits:.2e} (self-noise {noise_logits:.2e}); "
+          f"loss {hip_loss:.6f} vs {float(loss):.6f}; {len(rows)} gradient tensors: mean err {mean_e:.2e} (self-noise "
+          f"{mean_n:.2e}), worst {worst[0]} {worst[1]:.2e} (its self-noise {worst[2]:.2e}); {zero_branch} zero-gradient "
+          f"branch tensors exact")
+    if gamma_last:
+        for kind in ("conv1.weight", "conv2.weight", "conv3.weight", "bn1.weight", "bn2.weight", "bn3.weight"):
+            sel = [r for r in rows if r[0].endswith(kind)]
+            print(f"  {kind:14s} {len(sel):3d} tensors: HIP mean {sum(r[1] for r in sel) / len(sel):.2e} worst "
+                  f"{max(r[1] for r in sel):.2e} | yardstick mean {sum(r[2] for r in sel) / len(sel):.2e} worst "
+                  f"{max(r[2] for r in sel):.2e}")
     # the yardstick itself
-    assert noise_logits <= 5e-3 and mean_n <= 4e-2 and max(r[2] for r in rows) <= 6e-2, (noise_logits, mean_n)
-    assert zero_branch >= 48 * 2 and len(rows) >= 40
+    if gamma_last:
+        assert zero_branch == 0 and len(rows) == 161            # every parameter tensor has a non-zero gradient
+        assert noise_logits <= 8e-3 and mean_n <= 0.13 and max(r[2] for r in rows) <= 0.22, (noise_logits, mean_n)
+    else:
+        assert noise_logits <= 5e-3 and mean_n <= 4e-2 and max(r[2] for r in rows) <= 6e-2, (noise_logits, mean_n)
+        assert zero_branch >= 48 * 2 and len(rows) >= 40
     # the HIP path against it
     assert err_logits <= 2.0 * max(noise_logits, 1e-3)
     assert abs(hip_loss - float(loss)) <= 1e-3 * abs(float(loss))
@@ -170,25 +197,25 @@ def test_resnet50_whole_network_parity_well_conditioned():
 
 
 def test_resnet50_loss_curve_tracks_oracle():
-    """north_star: "loss curve matching CPU reference to 1e-3".  16 optimizer steps of the reference recipe (AdamW, label
+    """north_star: "loss curve matching CPU reference to 1e-3".  24 optimizer steps of the reference recipe (AdamW, label
     smoothing 0.1, lr warming up linearly from 0 as the reference's cosine_scheduler does, wd 5e-4; /root/reference/
     engine.py:46-77) on four 32-image batches cycled, from identical timm-default weights:
       * the CPU oracle with ITS OWN gradients (torch autograd, bf16 rounding points, torch.optim.AdamW),
       * the same in fp64 (how far two correct implementations drift apart: the yardstick),
       * imageclassification_amd.engine.train_one_epoch on the GPU.
-    The loss falls from 2.38 to ~1.1 as the batches are memorised.  Per step, the HIP loss must be within 1e-3 (relative) of
-    the oracle's over the first 12 steps, and everywhere within max(1e-3, 3x the largest drift the oracle's fp64 twin has
-    shown up to that step) -- once two correct trajectories have parted by d, later steps inherit it.  The table and the
-    step at which each pair first parts by more than 1e-3 are printed.  (Measured on MI355X over 24 steps, loss 2.38 -> 0.54:
-    HIP within 6.4e-4 for 21 steps, 1.2e-3 at one step; the same oracle code on two different host CPUs differs by 4e-4 at
-    step 2 already.)"""
+    The loss falls from 2.38 to ~0.54 as the batches are memorised.  ONE tolerance rule, for every step i: the HIP loss is
+    within max(1e-3, 3 x D_i) (relative) of the oracle's, D_i = the largest distance the oracle's own fp64 twin has shown up
+    to step i -- once two correct trajectories have parted by d, later steps inherit it; and at least 20 of the 24 steps
+    must sit within the plain 1e-3.  The table and the step at which each pair first parts by more than 1e-3 are printed.
+    (Measured on MI355X in round 2: HIP within 6.4e-4 for 21 steps, 1.2e-3 at step 21 where the fp64 twin had already shown
+    7.3e-4; the same oracle code on two different host CPUs differs by 4e-4 at step 2 already.)"""
     import copy
     from imageclassification_amd.engine import LOG_RING, train_one_epoch
     from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
     from imageclassification_amd.optim_factory import create_optimizer
     from imageclassification_amd.utils import NativeScalerWithGradNormCount
     from oracle import engine_ref as E
-    C, B, HW, steps, nb = 10, 32, 128, 16, 4
+    C, B, HW, steps, nb = 10, 32, 128, 24, 4
     ref, net = _timm_default_pair("resnet50", C)
     ref64 = copy.deepcopy(ref).double()
     g = torch.Generator().manual_seed(5)
@@ -221,13 +248,14 @@ def test_resnet50_loss_curve_tracks_oracle():
         print(f"{i:4d}   {l_ref[i]:.6f}    {l_64[i]:.6f}     {l_hip[i]:.6f}    {d_hip[i]:.2e}            {d_self[i]:.2e}")
     part = lambda d: next((i for i, v in enumerate(d) if v > 1e-3), None)   # noqa: E731
     print(f"first step parted by > 1e-3: HIP {part(d_hip)}, oracle fp64 {part(d_self)} (None = never in {steps} steps)")
-    assert l_ref[-1] < 0.65 * l_ref[0]                      # a real curve: the loss moved
+    assert l_ref[-1] < 0.35 * l_ref[0]                      # a real curve: the loss moved
     assert abs(stats["loss"] - sum(l_ref) / steps) <= 1e-3 * sum(l_ref) / steps
     assert opt.steps_taken == steps
     drift = 0.0
     for i in range(steps):
         drift = max(drift, d_self[i])
-        assert d_hip[i] <= (1e-3 if i < 12 else max(1e-3, 3.0 * drift)), (i, d_hip[i], drift)
+        assert d_hip[i] <= max(1e-3, 3.0 * drift), (i, d_hip[i], drift)
+    assert sum(1 for v in d_hip if v <= 1e-3) >= 20, d_hip
 
 
 @pytest.mark.parametrize("arch,B,HW,tol", [("resnet18", 8, 64, 3e-2), ("resnet50", 4, 96, 8e-2)])

@@ -149,6 +149,58 @@ def test_product_mixup_draws_equal_oracle_mixup():
             assert torch.allclose(soft, R.soft_targets(torch.arange(4) % 7, (torch.arange(4) % 7).flip(0), lam, 0.1, 7))
 
 
+def test_reference_style_mixup_object_draws_like_the_product_sampler():
+    """engine.train_one_epoch accepts the reference's `mixup_fn` (timm.data.Mixup, train.py:176-185): an object that only
+    carries timm's public fields draws exactly what this package's Mixup draws; live `mixup_enabled` flips are honoured;
+    unsupported modes / foreign objects raise."""
+    from types import SimpleNamespace
+    from imageclassification_amd.mixup import Mixup, sample_params
+    kw = dict(mixup_alpha=0.8, cutmix_alpha=1.0, cutmix_minmax=None, mix_prob=0.9, switch_prob=0.5, mode="batch",
+              correct_lam=True, label_smoothing=0.1, num_classes=7, mixup_enabled=True)
+    ref_style = SimpleNamespace(**kw)
+    np.random.seed(11)
+    a = [sample_params(ref_style, (4, 3, 32, 40)) for _ in range(30)]
+    np.random.seed(11)
+    own = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, prob=0.9, label_smoothing=0.1, num_classes=7)
+    b = [own.sample((4, 3, 32, 40)) for _ in range(30)]
+    assert a == b and {m for m, _, _ in a} == {0, 1, 2}
+    ref_style.mixup_enabled = False          # timm's mixup_off_epoch
+    assert sample_params(ref_style, (4, 3, 32, 40)) == (0, 1.0, (0, 0, 0, 0))
+    with pytest.raises(ValueError, match="elem"):
+        sample_params(SimpleNamespace(**dict(kw, mode="elem")), (4, 3, 8, 8))
+    with pytest.raises(TypeError, match="switch_prob"):
+        sample_params(SimpleNamespace(mixup_alpha=1.0, cutmix_alpha=0.0, mix_prob=1.0, label_smoothing=0.1, num_classes=3),
+                      (4, 3, 8, 8))
+
+
+def test_bench_self_launches_its_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE (the way the driver starts N = 1) must start N rank processes itself:
+    fresh children of torch.distributed.run, before torch is imported in the parent (reference entry:
+    `torchrun --nproc_per_node=N train.py`, README.md:21).  Here the launch command is captured instead of run."""
+    import importlib
+    import subprocess
+    import sys as _sys
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench = importlib.import_module("bench")
+    assert not hasattr(bench, "torch"), "bench.py must not import torch at module level (the launcher parent stays GPU-free)"
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the launcher's return code is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert cmd[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch" not in vars(bench), "the parent imported torch before launching"
+
+
 def test_meters_match_reference_semantics():
     from imageclassification_amd.utils import MetricLogger, SmoothedValue
     m = SmoothedValue(window_size=4)

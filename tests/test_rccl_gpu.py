@@ -72,7 +72,7 @@ def test_reducer_on_rccl_matches_the_undistributed_step(nccl_world1):
 
     def run(wrap):
         net = ResNet("resnet18", C, seed=11)
-        model = DistributedDataParallel(net, force=True, first_bucket_mb=0.25, bucket_mb=8.0, last_bucket_mb=1.0) if wrap else net
+        model = DistributedDataParallel(net, force=True, transport="rccl", first_bucket_mb=0.25, bucket_mb=8.0, last_bucket_mb=1.0) if wrap else net
         opt = create_optimizer("adamw", 1e-3, 5e-4, net)
         train_one_epoch(model, LabelSmoothingCrossEntropy(0.1), data, opt, DEV, 0, NativeScalerWithGradNormCount(), None,
                         None, None, start_steps=0, lr_schedule_values=[1e-3, 1e-3], wd_schedule_values=[5e-4, 5e-4],
@@ -85,6 +85,9 @@ def test_reducer_on_rccl_matches_the_undistributed_step(nccl_world1):
     red = model.reducer
     assert red.transport == "rccl" and red.comm is not None and red.ranks_seen() == 1
     assert len(red.buckets) >= 4
+    # per-bucket optimizer: K launches on the side stream, each enqueued right behind its bucket's all-reduce (stream order =
+    # event order), and the result is bit-identical to the single launch of the undistributed step
+    assert red.callbacks == red.launched and len(red.callbacks) == 2 * len(red.buckets)
     assert torch.equal(net.param_arena, plain.param_arena)
     assert torch.equal(net.grad_arena, plain.grad_arena)
     # non-finite loss: the flag travels through the MIN all-reduce and the step is dropped
@@ -96,3 +99,31 @@ def test_reducer_on_rccl_matches_the_undistributed_step(nccl_world1):
                     None, start_steps=0, lr_schedule_values=[1e-2], wd_schedule_values=[0.0],
                     num_training_steps_per_epoch=1, update_freq=1, use_amp=True, num_classes=C)
     assert torch.equal(net.param_arena, before) and opt.steps_taken == 0
+
+
+def _two_gpu_run(transport):
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", ICAMD_RANK_BACKEND="nccl")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ddp_gpu_worker.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), worker, "--transport", transport, "resnet18"]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL with more than one rank")
+@pytest.mark.parametrize("transport", ["torch", "rccl"])
+def test_two_gpu_reduced_gradient_is_the_mean_and_flag_propagates(transport):
+    """Two ranks on two GPUs over RCCL (fresh child processes of torch.distributed.run): the reducer's result times 1/world
+    is the mean of the ranks' gradients, a non-finite loss on ONE rank drops the step on BOTH (MIN-reduced flag), parameters
+    stay bit-identical across ranks, and the library's own communicator is destroyed on shutdown.  Runs wherever the suite
+    sees two devices (the single-GPU box skips it; tests/test_ddp_gpu.py rehearses the same worker over gloo there)."""
+    r = _two_gpu_run(transport)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert f"rccl2-ok {transport}" in r.stdout

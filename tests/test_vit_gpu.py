@@ -54,11 +54,14 @@ def test_token_plumbing_kernels():
     assert torch.equal(dst.cpu(), tok[:, 0].cpu())
 
 
-@pytest.mark.parametrize("img,B", [(64, 6), (224, 2)])
-def test_vit_forward_backward_matches_oracle(img, B):
+@pytest.mark.parametrize("arch,img,B", [("vit_tiny_test", 64, 6), ("vit_tiny_test", 224, 2),
+                                        # ViT-B/16 at its true width and depth (D 768, 12 heads, MLP 3072, 12 blocks, T 197):
+                                        # every gradient tensor against the oracle's, not only the loss
+                                        ("vit_base_patch16_224", 224, 2)])
+def test_vit_forward_backward_matches_oracle(arch, img, B):
     from imageclassification_amd import hip
     C = 10
-    ref, net = _pair("vit_tiny_test", C, img)
+    ref, net = _pair(arch, C, img)
     ref64 = copy.deepcopy(ref).double()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, 3, img, img, generator=g)
@@ -90,7 +93,7 @@ def test_vit_forward_backward_matches_oracle(img, B):
         if e > worst[1]:
             worst = (name, e)
         assert e <= 3.0 * max(n, 1e-2), (name, e, n)
-    print(f"vit img{img}: logits err {err:.2e} (self-noise {noise:.2e}); worst grad err {worst[1]:.2e} at {worst[0]}")
+    print(f"{arch} img{img}: logits err {err:.2e} (self-noise {noise:.2e}); worst grad err {worst[1]:.2e} at {worst[0]}")
 
 
 def test_vit_base_parameter_layout_and_engine_step():
