@@ -82,13 +82,13 @@ class GpuImagePipeline:
         total = sum(int(im.shape[0]) * int(im.shape[1]) * 3 for im in images)
         total_al = (total + 255) // 256 * 256
         dsize = ctypes.sizeof(descs)
-        k = self._turn
-        self._turn = 1 - k
-        if self._copied[k] is not None:
-            self._copied[k].synchronize()        # the upload that last read this buffer (two batches ago) has finished
-        if self._pinned[k] is None or self._pinned[k].numel() < total_al + dsize:
-            self._pinned[k] = torch.empty(max(total_al + dsize, 1 << 20), dtype=torch.uint8).pin_memory()
-        host = self._pinned[k].numpy()
+        slot = self._turn
+        self._turn = 1 - slot
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()     # the upload that last read this buffer (two batches ago) has finished
+        if self._pinned[slot] is None or self._pinned[slot].numel() < total_al + dsize:
+            self._pinned[slot] = torch.empty(max(total_al + dsize, 1 << 20), dtype=torch.uint8).pin_memory()
+        host = self._pinned[slot].numpy()
         off, max_crop, kmax = 0, 1, 3
         for i, (im, pr) in enumerate(zip(images, params)):
             if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
@@ -118,10 +118,10 @@ class GpuImagePipeline:
             off += n
         host[total_al:total_al + dsize] = np.frombuffer(bytes(descs), dtype=np.uint8)
         staged = torch.empty(total_al + dsize, dtype=torch.uint8, device=self.device)
-        staged.copy_(self._pinned[k][:total_al + dsize], non_blocking=True)      # one async upload: images + descriptors
+        staged.copy_(self._pinned[slot][:total_al + dsize], non_blocking=True)      # one async upload: images + descriptors
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self._copied[k] = ev
+        self._copied[slot] = ev
         src, ddev = staged[:total], staged[total_al:]
         need = self.lib.icamd_image_pipeline_workspace_bytes(B, max_crop, S, S, kmax)
         if self._ws is None or self._ws.numel() < need:

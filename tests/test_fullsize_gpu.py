@@ -157,7 +157,8 @@ def test_convnext_tiny_config4_full_batch_properties():
         st = train_one_epoch(net, SoftTargetCrossEntropy(), [(xc, yc)], opt, DEV, 0, NativeScalerWithGradNormCount(), None, ema,
                              mixer, start_steps=i, lr_schedule_values=[1e-3] * 3, wd_schedule_values=[5e-2] * 3,
                              num_training_steps_per_epoch=1, update_freq=1, use_amp=True, num_classes=C)
-        assert np.isfinite(st["loss"]) and 6.0 < st["loss"] < 8.0 and 0.0 <= st["class_acc"] <= 1.0
+        # ~ln(1000) at init; the same 256 images again at lr 1e-3 are memorised fast (4.3 at the third step, measured)
+        assert np.isfinite(st["loss"]) and (6.0 if i == 0 else 1.0) < st["loss"] < 8.0 and 0.0 <= st["class_acc"] <= 1.0
         expect = expect + (1.0 - decay) * (net.param_arena - expect)
         moved += float((net.param_arena - before).abs().max())
     assert moved > 0 and opt.steps_taken == 3
