@@ -42,13 +42,130 @@ __device__ __forceinline__ void wait_loads(int stages_younger) {   // LPW LDS-DM
   }
 }
 
+// ---- epilogue shared by both kernels: MFMA layout -> bias/addend -> bf16 -> LDS [256][TN] (chunk ^= row & (CPR-1)) ->
+// coalesced rows.  acc[j][i]: rows wm*128 + i*16 + fr, channels wn*64 + j*16 + 4*fq .. +3.  The caller has made sure every
+// wave is done reading the operand tiles (the output tile reuses that LDS).
+template <int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmNtParams& p, unsigned char* smem, f32x4 (&acc)[4][8], int wm, int wn,
+                                              int m0, int n0, int tile_m) {
+  constexpr int ROWB = TN * 2, CPR = TN / 8;  // epilogue tile: bytes and 16 B chunks per row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- epilogue: MFMA layout -> bias/addend -> bf16 -> LDS [256][TN] (chunk ^= row & (CPR-1)) -> coalesced rows ----
+  long long aoff[8];      // addend row offsets of this lane's 8 rows; < 0: the row has no addend
+  if (p.addend != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ml = wm * 128 + i * 16 + fr;
+      const unsigned int mr = (m0 + ml < p.M) ? m0 + ml : 0;
+      if (p.sub2_h > 0) {   // addend on the even pixel grid only (see icamd_conv2d_dgrad_sub2)
+        const unsigned int n = fdiv(mr, p.divHW);
+        const unsigned int rem = mr - n * (p.sub2_h * p.sub2_w);
+        const unsigned int hh = fdiv(rem, p.divW);
+        const unsigned int ww = rem - hh * p.sub2_w;
+        const long long r = ((long long)n * ((p.sub2_h + 1) >> 1) + (hh >> 1)) * ((p.sub2_w + 1) >> 1) + (ww >> 1);
+        aoff[i] = ((hh | ww) & 1u) ? -1 : r * p.N;
+      } else {
+        aoff[i] = (long long)mr * p.N;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cl = wn * 64 + j * 16 + 4 * fq;
+    const int cg = n0 + cl;
+    const int cgc = cg < p.N ? cg : 0;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ml = wm * 128 + i * 16 + fr;
+      f32x4 v = acc[j][i] + b4;
+      if (p.addend != nullptr && aoff[i] >= 0) {
+        const u32x2 a = *(const u32x2*)(p.addend + aoff[i] + cgc);
+        unsigned int ab = 0xfu;
+        if (p.addend_bits != nullptr)   // this lane's 4 channels are one nibble of the element's mask byte
+          ab = ((unsigned int)p.addend_bits[(aoff[i] + cgc) >> 3] >> (4 * (fq & 1))) & 0xfu;
+        v[0] += (ab & 1u) ? bf16_lo(a[0]) : 0.f;
+        v[1] += (ab & 2u) ? bf16_hi(a[0]) : 0.f;
+        v[2] += (ab & 4u) ? bf16_lo(a[1]) : 0.f;
+        v[3] += (ab & 8u) ? bf16_hi(a[1]) : 0.f;
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+      }
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      const int slot = cl >> 2;
+      *(u32x2*)(smem + ml * ROWB + ((((slot >> 1) ^ ml) & (CPR - 1)) << 4) + ((slot & 1) << 3)) = pk;
+    }
+  }
+  __syncthreads();
+  constexpr int RPP = (TN * 2) / CPR;   // rows per pass of the whole workgroup
+  const int cp = tid & (CPR - 1), rg = tid / CPR;
+  const int co = n0 + cp * 8;
+  const bool want_stats = p.stats != nullptr;   // uniform
+  f32x2 s1[4], s2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
+#pragma unroll 4
+  for (int ps = 0; ps < TM / RPP; ++ps) {
+    const int ml = ps * RPP + rg;
+    const int m = m0 + ml;
+    u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ ml) & (CPR - 1)) << 4));
+    if (m < p.M && co < p.N) {
+      const long long off = (long long)m * p.N + co;
+      if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
+      if (p.gelu_inplace) o = gelu8(o);
+      *(u32x4*)(p.out + off) = o;
+      if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x2 v = {bf16_lo(o[e]), bf16_hi(o[e])};
+          s1[e] += v;
+          s2[e] = __builtin_elementwise_fma(v, v, s2[e]);
+        }
+      }
+    }
+  }
+  if (want_stats) {
+    // BatchNorm statistics of the rounded outputs: one partial row per 256-row tile (row tile_m of the [ceil(M/128)] table
+    // the consumer sums); the rows no tile owns are zero-filled by the tile whose index they exceed the tile count by
+    __syncthreads();
+    float* red = (float*)smem;             // [RPP][2][TN]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[(rg * 2 + 0) * TN + cp * 8 + 2 * e] = s1[e][0];
+      red[(rg * 2 + 0) * TN + cp * 8 + 2 * e + 1] = s1[e][1];
+      red[(rg * 2 + 1) * TN + cp * 8 + 2 * e] = s2[e][0];
+      red[(rg * 2 + 1) * TN + cp * 8 + 2 * e + 1] = s2[e][1];
+    }
+    __syncthreads();
+    const int ntm = (p.M + TM - 1) / TM, nrows = (p.M + 127) / 128;
+    for (int idx = tid; idx < 2 * TN; idx += TN * 2) {
+      const int which = idx / TN, c = idx - which * TN;
+      float s = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * TN + c];
+      if (n0 + c < p.N) {
+        p.stats[((long long)tile_m * 2 + which) * p.N + n0 + c] = s;
+        if (ntm + tile_m < nrows) p.stats[((long long)(ntm + tile_m) * 2 + which) * p.N + n0 + c] = 0.f;
+      }
+    }
+  }
+}
+
 template <int TN>
 __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p) {
   constexpr int NSLOT = TN == 256 ? 4 : 3;   // ring depth: one 8-wave workgroup per CU can afford a fourth slot
   constexpr int NW = TN / 32;                 // waves: 2 along M x TN/64 along N
   constexpr int STAGE = (TM + TN) * TK * 2;   // bytes per ring slot
   constexpr int AI = 16 / NW, BI = (TN / 16) / NW, LPW = AI + BI;   // LDS-DMA instructions per wave and stage
-  constexpr int ROWB = TN * 2, CPR = TN / 8;  // epilogue tile: bytes and 16 B chunks per row
+  constexpr int ROWB = TN * 2;                // epilogue tile: bytes per row
   constexpr int LDSB = NSLOT * STAGE > TM * ROWB ? NSLOT * STAGE : TM * ROWB;   // the output tile reuses the ring
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDSB];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -165,116 +282,200 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
     for (int j = 0; j < 4; ++j)
       acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
   __syncthreads();   // all fragment reads done: the ring becomes the output tile
-
-  // ---- epilogue: MFMA layout -> bias/addend -> bf16 -> LDS [256][TN] (chunk ^= row & (CPR-1)) -> coalesced rows ----
-  long long aoff[8];      // addend row offsets of this lane's 8 rows; < 0: the row has no addend
-  if (p.addend != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ml = wm * 128 + i * 16 + fr;
-      const unsigned int mr = (m0 + ml < p.M) ? m0 + ml : 0;
-      if (p.sub2_h > 0) {   // addend on the even pixel grid only (see icamd_conv2d_dgrad_sub2)
-        const unsigned int n = fdiv(mr, p.divHW);
-        const unsigned int rem = mr - n * (p.sub2_h * p.sub2_w);
-        const unsigned int hh = fdiv(rem, p.divW);
-        const unsigned int ww = rem - hh * p.sub2_w;
-        const long long r = ((long long)n * ((p.sub2_h + 1) >> 1) + (hh >> 1)) * ((p.sub2_w + 1) >> 1) + (ww >> 1);
-        aoff[i] = ((hh | ww) & 1u) ? -1 : r * p.N;
-      } else {
-        aoff[i] = (long long)mr * p.N;
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int cl = wn * 64 + j * 16 + 4 * fq;
-    const int cg = n0 + cl;
-    const int cgc = cg < p.N ? cg : 0;
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ml = wm * 128 + i * 16 + fr;
-      f32x4 v = acc[j][i] + b4;
-      if (p.addend != nullptr && aoff[i] >= 0) {
-        const u32x2 a = *(const u32x2*)(p.addend + aoff[i] + cgc);
-        unsigned int ab = 0xfu;
-        if (p.addend_bits != nullptr)   // this lane's 4 channels are one nibble of the element's mask byte
-          ab = ((unsigned int)p.addend_bits[(aoff[i] + cgc) >> 3] >> (4 * (fq & 1))) & 0xfu;
-        v[0] += (ab & 1u) ? bf16_lo(a[0]) : 0.f;
-        v[1] += (ab & 2u) ? bf16_hi(a[0]) : 0.f;
-        v[2] += (ab & 4u) ? bf16_lo(a[1]) : 0.f;
-        v[3] += (ab & 8u) ? bf16_hi(a[1]) : 0.f;
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
-      }
-      u32x2 pk;
-      pk[0] = pack_bf16x2(v[0], v[1]);
-      pk[1] = pack_bf16x2(v[2], v[3]);
-      const int slot = cl >> 2;
-      *(u32x2*)(smem + ml * ROWB + ((((slot >> 1) ^ ml) & (CPR - 1)) << 4) + ((slot & 1) << 3)) = pk;
-    }
-  }
-  __syncthreads();
-  constexpr int RPP = (TN * 2) / CPR;   // rows per pass of the whole workgroup
-  const int cp = tid & (CPR - 1), rg = tid / CPR;
-  const int co = n0 + cp * 8;
-  const bool want_stats = p.stats != nullptr;   // uniform
-  f32x2 s1[4], s2[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
-#pragma unroll 4
-  for (int ps = 0; ps < TM / RPP; ++ps) {
-    const int ml = ps * RPP + rg;
-    const int m = m0 + ml;
-    u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ ml) & (CPR - 1)) << 4));
-    if (m < p.M && co < p.N) {
-      const long long off = (long long)m * p.N + co;
-      if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
-      if (p.gelu_inplace) o = gelu8(o);
-      *(u32x4*)(p.out + off) = o;
-      if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
-      if (want_stats) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f32x2 v = {bf16_lo(o[e]), bf16_hi(o[e])};
-          s1[e] += v;
-          s2[e] = __builtin_elementwise_fma(v, v, s2[e]);
-        }
-      }
-    }
-  }
-  if (want_stats) {
-    // BatchNorm statistics of the rounded outputs: one partial row per 256-row tile (row tile_m of the [ceil(M/128)] table
-    // the consumer sums); the rows no tile owns are zero-filled by the tile whose index they exceed the tile count by
-    __syncthreads();
-    float* red = (float*)smem;             // [RPP][2][TN]
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[(rg * 2 + 0) * TN + cp * 8 + 2 * e] = s1[e][0];
-      red[(rg * 2 + 0) * TN + cp * 8 + 2 * e + 1] = s1[e][1];
-      red[(rg * 2 + 1) * TN + cp * 8 + 2 * e] = s2[e][0];
-      red[(rg * 2 + 1) * TN + cp * 8 + 2 * e + 1] = s2[e][1];
-    }
-    __syncthreads();
-    const int ntm = (p.M + TM - 1) / TM, nrows = (p.M + 127) / 128;
-    for (int idx = tid; idx < 2 * TN; idx += TN * 2) {
-      const int which = idx / TN, c = idx - which * TN;
-      float s = 0.f;
-#pragma unroll 4
-      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * TN + c];
-      if (n0 + c < p.N) {
-        p.stats[((long long)tile_m * 2 + which) * p.N + n0 + c] = s;
-        if (ntm + tile_m < nrows) p.stats[((long long)(ntm + tile_m) * 2 + which) * p.N + n0 + c] = 0.f;
-      }
-    }
-  }
+  gemm_epilogue<TN>(p, smem, acc, wm, wn, m0, n0, tile_m);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, eight phases per pair of 64-deep K tiles (cdna_hip_programming.md "The 256^2 8-phase template"), for the
+// MFMA-bound problems (ViT-B/16's Linear layers: M = 50 432, N, K in {768, 2304, 3072}).
+//
+//   * 8 waves, wr = wave >> 2 owns rows wr*128 .. +128, wc = wave & 3 owns channels wc*64 .. +64: 128 x 64 accumulators per
+//     wave = four QUADRANTS of 64 rows x 32 channels, one per phase: 16 MFMAs (4 row fragments x 2 channel fragments x 2
+//     k-steps) between two raw s_barriers.
+//   * The K tile is staged as four PIECES of 16 KB, cut so that a piece is exactly what one phase starts to need:
+//       A_mh0 = rows {wr*128 + [0, 64)}  (phase 1)    B_nh0 = channels {wc*64 + [0, 32)}   (phase 1, kept for phase 4)
+//       B_nh1 = channels {wc*64 + [32, 64)} (phase 2)  A_mh1 = rows {wr*128 + [64, 128)}    (phase 3)
+//     a piece = [128 rows][128 B = the K tile's 64 elements] (16 B chunks XOR-swizzled by (row >> 1) & 7), filled by 16
+//     LDS-DMA wave-instructions (2 per wave) of 8 rows x one whole 128 B line each.  LDS holds two K tiles (128 KB).  Every
+//     phase issues ONE piece, six pieces ahead of the phase that runs: a piece is issued 5 phases before its first read and
+//     >= 2 phases after the last read of the piece it overwrites (two K tiles earlier).
+//   * The two wave groups (wr = 0 / 1: the two waves of every SIMD) run ONE BARRIER apart: while one group is between its
+//     barriers issuing 16 MFMAs (and, among them, the phase's two LDS-DMA instructions), the other is in its load section
+//     (ds_read_b128 of the next fragments and a counted s_waitcnt vmcnt(6) that leaves three pieces in flight).  A piece is
+//     read one phase after the wait that retires it (both groups have then passed a barrier behind their own waits).
+//   * Fragment reads are inline-asm ds_read_b128 with immediate offsets off per-lane base addresses (hipcc would put
+//     vmcnt(0) in front of C++ LDS loads while LDS-DMA is in flight); the LDS-DMA is inline asm too, in its scalar-base form
+//     (the builtin always takes a 64-bit per-lane address: 16 more VGPRs); all LDS is one array.
+//   * Measured (round 3, M = 50 432, N = 2304, K = 768, random operands): 834 TFLOP/s (the ring kernel: 659; the vendor GEMM
+//     behind torch.matmul: 955).  Ablations of the same instruction stream: made to re-read ONE K tile, so that every LDS-DMA
+//     hits L2, it runs at 1 270 TFLOP/s -- the rate of its MFMAs alone (no staging and no fragment reads: 1 263; without the
+//     barriers too: 1 273); on the real operands 29 % of the L2 requests miss (the 32 workgroups of an XCD share each A line
+//     9 ways and each B line 3-4 ways, so ~20 % of the staged bytes are first touches even in lockstep) and the waves sit in
+//     s_waitcnt / s_barrier for 54 % of their cycles.
+//     Tried on top and NOT kept: a persistent form (one workgroup per CU walking its tiles, the next tile's first six pieces
+//     issued under a wave-private epilogue): 5 % slower than letting the dispatcher place one workgroup per tile; on that
+//     form, L2 prefetch touches (one global_load_ubyte per wave and K tile over the 512 lines of the K tile four tiles ahead):
+//     11 % slower again -- the touches sit in the same in-order vmcnt queue as the LDS-DMA the load sections wait for;
+//     LDS-DMA issued in the load section instead of among the MFMAs: the same; a ring of ten piece slots (all 160 KB of LDS,
+//     two more pieces of lead): 5-11 % slower.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int PIECE = 16384, KTILE = 65536;   // bytes: one piece, one K tile (pieces in stream order A_mh0, B_nh0, B_nh1, A_mh1)
+
+// LDS-DMA of 16 B per lane with a SCALAR 64-bit base and a 32-bit per-lane byte offset.  M0 = the wave-uniform LDS
+// destination, as the builtin would set it; hipcc re-materialises M0 before every use of its own.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_sbase(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ void wait_pieces_younger(int n) {   // leave the n youngest pieces (2 LDS-DMA each) in flight
+  if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const GemmNtParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * KTILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = p.K / 64;
+  const int last_piece = 4 * nk - 1;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LPTR(smem));
+  // fragment rows are 16-aligned + fr, so the swizzle key (row >> 1) & 7 is a lane constant; k-step 1 is chunk ^ 4: a second
+  // base address (XOR 64) instead of an immediate.  With lane = 16*fq + fr every ds_read_b128 lane group covers the 16 slots
+  // of the 256 B bank span exactly once.
+  const unsigned sw = (unsigned)((fr >> 1) & 7);
+  const unsigned c0 = (((unsigned)fq ^ sw) & 7u) << 4;          // chunk (0*4 + fq) ^ sw
+  const unsigned aA0 = lds_base + (unsigned)((wr * 64 + fr) * 128) + c0, aA1 = aA0 + KTILE;
+  const unsigned aB0 = lds_base + (unsigned)((wc * 32 + fr) * 128) + c0, aB1 = aB0 + KTILE;
+  const unsigned char* const Ab = (const unsigned char*)p.A;
+  const unsigned char* const Bb = (const unsigned char*)p.B;
+  const unsigned rowb = (unsigned)p.K * 2u;                      // operand row pitch in bytes
+
+  // XCD-aware tile order (blocks b and b + 8 share an XCD): consecutive n-tiles of one m-tile stay on one XCD
+  unsigned int L;
+  {
+    const unsigned int nblk = gridDim.x;
+    const unsigned int xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned int q = nblk >> 3, r = nblk & 7u;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = L / p.ntiles_n, tile_n = L - tile_m * p.ntiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+
+  // staging roles: instruction j of this wave is instruction q = wave*2 + j of a piece: piece rows q*8 .. +8, EIGHT lanes per
+  // row = one whole 128 B line of the operand per row (the 16 B chunks permuted on the SOURCE side).  Per lane only a 32-bit
+  // byte offset from the operand's base (M*K*2 < 4 GB is checked by the launcher); the K tile enters through the scalar base.
+  // Rows past M / channels past N read the LAST valid row instead: valid memory, and what they produce is never stored.
+  unsigned off[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = wave * 2 + j;
+      const int r = q * 8 + (lane >> 3);
+      const int lc = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+      const bool isA = (t == 0 || t == 3);
+      const int grow = isA ? m0 + (r >> 6) * 128 + (t == 3 ? 64 : 0) + (r & 63) : n0 + (r >> 5) * 64 + (t == 2 ? 32 : 0) + (r & 31);
+      const int lim = isA ? p.M - 1 : p.N - 1;
+      off[t][j] = (unsigned)(grow < lim ? grow : lim) * rowb + (unsigned)lc;
+    }
+  auto stage1 = [&](auto tc, auto bc, auto jc, int ktile) {   // instruction J of piece type T of K tile `ktile` into buffer B
+    constexpr int T = decltype(tc)::value, B = decltype(bc)::value, J = decltype(jc)::value;
+    const unsigned char* kb = ((T == 0 || T == 3) ? Ab : Bb) + (size_t)ktile * 128;
+    glds16_sbase(kb, off[T][J], lds_base + (unsigned)(B * KTILE + T * PIECE + (wave * 2 + J) * 1024));
+  };
+  // prologue: pieces 0..5 (the whole first K tile and the first half of the second)
+  static_for<0, 6>([&](auto sc) {
+    constexpr int S = decltype(sc)::value;
+    if (S < 4 || nk > 1) {
+      stage1(std::integral_constant<int, (S & 3)>{}, std::integral_constant<int, (S >> 2)>{}, std::integral_constant<int, 0>{}, S >> 2);
+      stage1(std::integral_constant<int, (S & 3)>{}, std::integral_constant<int, (S >> 2)>{}, std::integral_constant<int, 1>{}, S >> 2);
+    }
+  });
+  wait_pieces_younger((nk > 1 ? 5 : 3) - 1);      // pieces 0 and 1 have landed (this wave's part)
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
+  bf16x8 af[8], b0[4], b1[4];   // A fragments [ks*4 + i] of the current row half; B fragments [ks*2 + j] of both channel halves
+
+  // STEADY: every piece this phase and the next ones touch exists (no end-of-K checks, constant wait counts)
+  auto phase = [&](auto phc, auto steadyc, int g) {
+    constexpr int PH = decltype(phc)::value;       // 0..7: K-tile parity PH >> 2, phase PH & 3
+    constexpr bool STEADY = decltype(steadyc)::value;
+    constexpr int BUF = PH >> 2, P = PH & 3;
+    const unsigned aA = BUF ? aA1 : aA0, aB = BUF ? aB1 : aB0;
+    // ---- load section: the fragments this phase starts to need, then the wait that retires what the NEXT phase reads
+    if constexpr (P == 0) {
+      static_for<0, 8>([&](auto c) { constexpr int x = decltype(c)::value; af[x] = lds_read128_off<0 * PIECE + (x & 3) * 2048>((x >> 2) ? aA ^ 64u : aA); });
+      static_for<0, 4>([&](auto c) { constexpr int x = decltype(c)::value; b0[x] = lds_read128_off<1 * PIECE + (x & 1) * 2048>((x >> 1) ? aB ^ 64u : aB); });
+    } else if constexpr (P == 1) {
+      static_for<0, 4>([&](auto c) { constexpr int x = decltype(c)::value; b1[x] = lds_read128_off<2 * PIECE + (x & 1) * 2048>((x >> 1) ? aB ^ 64u : aB); });
+    } else if constexpr (P == 2) {
+      static_for<0, 8>([&](auto c) { constexpr int x = decltype(c)::value; af[x] = lds_read128_off<3 * PIECE + (x & 3) * 2048>((x >> 2) ? aA ^ 64u : aA); });
+    }
+    // pieces <= g + 2 (what phase g + 1 starts to read) have landed; issued so far: pieces <= g + 5
+    if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else wait_pieces_younger((g + 5 < last_piece ? g + 5 : last_piece) - (g + 2));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
+                   "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute section: one quadrant, 16 MFMAs; among them the phase's piece (g + 6: type (PH + 2) & 3, K tile (g + 6) >> 2)
+    constexpr int MH = (P >= 2) ? 1 : 0, NH = (P == 1 || P == 2) ? 1 : 0;
+    const bool do_stage = STEADY || g + 6 <= last_piece;
+    const int ktile = (g + 6) >> 2;
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 16>([&](auto mc) {
+      constexpr int x = decltype(mc)::value;
+      constexpr int ks = x >> 3, i = (x >> 1) & 3, j = x & 1;
+      if constexpr (x == 3 || x == 10) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_stage) stage1(std::integral_constant<int, ((PH + 2) & 3)>{}, std::integral_constant<int, (((PH + 6) >> 2) & 1)>{},
+                             std::integral_constant<int, (x == 3 ? 0 : 1)>{}, ktile);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[NH * 2 + j][MH * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(NH ? b1[ks * 2 + j] : b0[ks * 2 + j], af[ks * 4 + i],
+                                                                           acc[NH * 2 + j][MH * 4 + i], 0, 0, 0);
+    });
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  int g = 0;
+  int t = 0;
+  for (; t + 2 <= nk && g + 13 <= last_piece; t += 2) {   // both K tiles' phases stage pieces that exist
+    static_for<0, 8>([&](auto phc) { phase(phc, std::true_type{}, g + decltype(phc)::value); });
+    g += 8;
+  }
+  for (; t + 2 <= nk; t += 2) {
+    static_for<0, 8>([&](auto phc) { phase(phc, std::false_type{}, g + decltype(phc)::value); });
+    g += 8;
+  }
+  if (nk & 1) static_for<0, 4>([&](auto phc) { phase(phc, std::false_type{}, g + decltype(phc)::value); });
+  if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the two groups
+  __syncthreads();                                 // every fragment read is done: the operand tiles become the output tile
+  gemm_epilogue<256>(p, smem, acc, wr, wc, m0, n0, tile_m);
+}
+
+// ICAMD_GEMM_TN: 128 / 256 force the ring kernel at that tile width; 8 (default) = the 8-phase 256 x 256 kernel wherever K is a
+// multiple of 64 (else the 128-wide ring)
 int tile_n_width() {
-  static const int tn = [] { const char* e = getenv("ICAMD_GEMM_TN"); return e && atoi(e) == 256 ? 256 : 128; }();
+  static const int tn = [] { const char* e = getenv("ICAMD_GEMM_TN"); const int v = e ? atoi(e) : 8; return v == 256 || v == 128 ? v : 8; }();
   return tn;
 }
 
@@ -296,14 +497,18 @@ bool icamd_gemm_nt_wanted(long long M, int N, int K) {
 
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream) {
   if (p.K % TK != 0 || p.N % 8 != 0 || p.M <= 0) return ICAMD_ERR_UNSUPPORTED;
-  const int tn = tile_n_width();
+  int tn = tile_n_width();
+  // (the 8-phase kernel addresses its operands with 32-bit byte offsets)
+  const bool eight = tn == 8 && p.K % 64 == 0 && (long long)p.M * p.K < (1ll << 31) && (long long)p.N * p.K < (1ll << 31);
+  if (tn == 8) tn = eight ? 256 : 128;
   p.ntiles_n = (p.N + tn - 1) / tn;
   if (p.sub2_h > 0) {
     p.divHW = make_fastdiv((unsigned)(p.sub2_h * p.sub2_w));
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
   const long long tiles = (long long)((p.M + TM - 1) / TM) * p.ntiles_n;
-  if (tn == 256) hipLaunchKernelGGL(gemm_nt_kernel<256>, dim3((unsigned)tiles), dim3(512), 0, stream, p);
+  if (eight) hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3((unsigned)tiles), dim3(512), 0, stream, p);
+  else if (tn == 256) hipLaunchKernelGGL(gemm_nt_kernel<256>, dim3((unsigned)tiles), dim3(512), 0, stream, p);
   else hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, stream, p);
   return icamd_launch_status();
 }

@@ -142,6 +142,7 @@ LARGE_POINTWISE = [
     (1, 129, 127, 288, 1000),   # ragged M and N, K = 9 stages
     (2, 197, 64, 768, 2304),    # ViT qkv shape at a small batch
     (8, 56, 56, 256, 256),      # Cin a multiple of 64: the mask-bit addend of the residual data gradient
+    (1, 300, 301, 128, 1000),   # 1412 ragged tiles of the persistent 8-phase kernel (several tiles per workgroup), two K tiles
 ]
 
 
@@ -238,9 +239,13 @@ def test_pointwise_register_resident_filter_every_shape():
     assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
 
 
-def test_pointwise_large_tile_gemm_forced_small_k():
+@pytest.mark.parametrize("tn", ["8", "128"])
+def test_pointwise_large_tile_gemm_forced_small_k(tn):
     """ICAMD_GEMM_NT=2 routes every eligible pointwise problem through gemm_nt.hip: covers 1-, 2- and 3-stage K loops and
-    tiles that are mostly padding.  The routing switch is read once per process, hence the child process."""
+    tiles that are mostly padding.  ICAMD_GEMM_TN=8 (the default) is the 8-phase 256 x 256 kernel wherever K % 64 == 0 --
+    K = 64 / 128 / 192 / 320 / 768: one, two, an odd number of K tiles (the 4-phase tail) and the pipelined steady state --
+    and the ring kernel elsewhere; 128 forces the ring kernel for all.  The switches are read once per process, hence the
+    child process."""
     import subprocess
     import sys
     code = (
@@ -248,10 +253,12 @@ def test_pointwise_large_tile_gemm_forced_small_k():
         "import test_kernels_gpu as T\n"
         "from imageclassification_amd import hip\n"
         "lib = hip.load()\n"
-        "T._run_large_pointwise(lib, [(1, 5, 7, 32, 40), (2, 9, 9, 64, 264), (1, 20, 20, 96, 512), (3, 16, 16, 160, 72)])\n"
+        "T._run_large_pointwise(lib, [(1, 5, 7, 32, 40), (2, 9, 9, 64, 264), (1, 20, 20, 96, 512), (3, 16, 16, 160, 72),\n"
+        "                             (1, 20, 20, 192, 512), (2, 9, 9, 320, 264), (1, 33, 31, 128, 520), (1, 40, 13, 768, 256)])\n"
+        "T._run_large_pointwise(lib, T.LARGE_POINTWISE)\n"
         "print('forced-ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, ICAMD_GEMM_NT="2")
+    env = dict(os.environ, ICAMD_GEMM_NT="2", ICAMD_GEMM_TN=tn)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
 

@@ -1,6 +1,6 @@
 """Time one pointwise forward (icamd_conv2d_fwd without statistics) at a ViT Linear shape. Usage: gemm_probe.py M N K"""
-import ctypes, sys, torch
-sys.path.insert(0, ".")
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imageclassification_amd import hip
 lib = hip.load()
 M, N, K = [int(a) for a in sys.argv[1:4]]
