@@ -7,6 +7,7 @@
 // in/out, fp32 accumulation, filters stored tap-major [7][7][C] (bf16 shadow of the fp32 master).
 #include "common.h"
 #include "icamd_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -182,6 +183,239 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Register sliding-window form (round 3).  The tile kernel above staged a halo tile in LDS and re-read every input vector
+// once per kernel row: 13 LDS reads + 13 unpacks per 49 multiply-adds, 296 us for stage 0 of ConvNeXt-T at batch 256 against
+// 38 us of HBM time and ~45 us of VALU time.  Here a thread owns TWO channels (one packed fp32 pair) of a strip of 7 output
+// columns and walks DOWN the image: the 49 taps (98 VGPRs) and a ring of 7 x 7 output accumulators (98 VGPRs) stay in
+// registers, every input row is loaded ONCE (13 dwords straight from global memory -- the lanes of a wave are consecutive
+// channel pairs, 256 B per pixel, so no LDS is needed for coalescing) and feeds all seven kernel rows: 343 v_pk_fma_f32 per
+// 13 loads + 26 unpacks.  Output row h - 3 is complete when input row h has been consumed; the next row's loads are in
+// flight under the current row's arithmetic.  flip = the data gradient (taps mirrored).
+// ------------------------------------------------------------------------------------------------------------------------
+template <bool ADD>
+__global__ __launch_bounds__(256, 2) void dwconv7_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, const bf16_t* __restrict__ addend,
+                                                              bf16_t* __restrict__ y, int N, int H, int W, int C, int flip,
+                                                              int nstrips, int hsplit, unsigned int total, unsigned int last_off) {
+  // blockIdx.y = which part of the image rows (uniform: every row test below is a scalar branch); blockIdx.x * 256 + tid walks
+  // (channel pair, strip, image) with the channel pairs fastest: the lanes of a wave read consecutive dwords of a pixel
+  const unsigned int t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= total) return;
+  const int cpr = C >> 1;
+  const int cp = (int)(t % (unsigned)cpr);
+  unsigned int q = t / (unsigned)cpr;
+  const int strip = (int)(q % (unsigned)nstrips);
+  const int n = (int)(q / (unsigned)nstrips);
+  const int rows_per = (H + hsplit - 1) / hsplit;
+  const int h0 = blockIdx.y * rows_per, h1 = (H < h0 + rows_per) ? H : h0 + rows_per;
+  if (h0 >= h1) return;
+  const int c = cp * 2, w0 = strip * 7;
+  // the taps: kernel rows 0..5 in registers (84 VGPRs), row 6 in LDS (this thread's own 7 pairs, read back once per input
+  // row: all 49 in registers leave hipcc four VGPRs short and it spills two taps INTO the row loop)
+  __shared__ f32x2 w6[7][256];
+  f32x2 wv[42];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) {
+    const unsigned int raw = *(const unsigned int*)(w + (long long)(flip ? 48 - k : k) * C + c);
+    if (k < 42) wv[k] = f32x2{bf16_lo(raw), bf16_hi(raw)};
+    else w6[k - 42][threadIdx.x] = f32x2{bf16_lo(raw), bf16_hi(raw)};
+  }
+  const f32x2 b2 = (bias != nullptr) ? f32x2{bias[c], bias[c + 1]} : f32x2{0.f, 0.f};
+  unsigned int colmask = 0;                      // bit j: input column w0 - 3 + j is inside the image
+#pragma unroll
+  for (int j = 0; j < 13; ++j) colmask |= ((unsigned)(w0 - 3 + j) < (unsigned)W ? 1u : 0u) << j;
+  // 32-bit byte offsets from the (uniform) tensor bases (the launcher checks the tensors are < 4 GB).  Columns outside the
+  // image are read from a CLAMPED offset (any valid dword) and replaced by zero with a select: no exec-mask branch per load.
+  const unsigned int cb = (unsigned)C * 2u, rowb = (unsigned)W * cb;
+  const unsigned int img = (unsigned)n * (unsigned)H * rowb;
+  const unsigned int xo = img + (unsigned)(w0 - 3) * cb + (unsigned)c * 2u;   // + h * rowb + j * cb (wraps for w0 < 3: clamped)
+  const unsigned int yo = img + (unsigned)w0 * cb + (unsigned)c * 2u;
+  const unsigned char* const xB = (const unsigned char*)x;
+  const unsigned char* const aB = (const unsigned char*)addend;
+  unsigned char* const yB = (unsigned char*)y;
+  const int lo = h0 - 3 > 0 ? h0 - 3 : 0, hi_end = h1 + 3 < H ? h1 + 3 : H;   // input rows that exist and matter
+  f32x2 acc[7][7];
+  // ADD (the data gradient's residual addend): an output row's accumulators START from its addend row, loaded when the ring
+  // slot is recycled -- a whole input row of arithmetic before the slot's first multiply-add -- instead of 7 exposed loads in
+  // front of every row's stores
+  auto init_slot = [&](auto slotc, int ho) {
+    constexpr int S = decltype(slotc)::value;
+    if (ADD && ho < h1) {
+      const unsigned int orow = yo + (unsigned)ho * rowb;
+#pragma unroll
+      for (int o = 0; o < 7; ++o) {
+        const unsigned int off = orow + (unsigned)o * cb;
+        const unsigned int a = *(const unsigned int*)(aB + (off < last_off ? off : last_off));
+        acc[S][o] = f32x2{bf16_lo(a), bf16_hi(a)};            // (columns past W: never stored)
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < 7; ++o) acc[S][o] = b2;
+    }
+  };
+  static_for<0, 7>([&](auto sc) {                             // slot s first serves the output row ho >= h0 with ho % 7 == s
+    constexpr int S = decltype(sc)::value;
+    init_slot(sc, h0 + ((S - h0 % 7) + 7) % 7);
+  });
+  unsigned int nxt[13];
+  auto load_row = [&](int h) {
+    const unsigned int ro = xo + (unsigned)h * rowb;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const unsigned int off = ro + (unsigned)j * cb;
+      const unsigned int v = *(const unsigned int*)(xB + (off < last_off ? off : last_off));
+      nxt[j] = ((colmask >> j) & 1u) ? v : 0u;
+    }
+  };
+  load_row(lo);
+  for (int base = lo / 7 * 7; base < h1 + 3; base += 7) {
+    static_for<0, 7>([&](auto kc) {
+      constexpr int K = decltype(kc)::value;     // = hi % 7
+      const int hi = base + K;
+      if (hi >= lo && hi < h1 + 3) {
+        if (hi < hi_end) {
+          f32x2 xu[13];
+#pragma unroll
+          for (int j = 0; j < 13; ++j) xu[j] = f32x2{bf16_lo(nxt[j]), bf16_hi(nxt[j])};
+          if (hi + 1 < hi_end) load_row(hi + 1);             // in flight under this row's arithmetic
+          static_for<0, 7>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;           // kernel row: output row ho = hi - R + 3, ring slot ho % 7
+            constexpr int SLOT = (K - R + 3 + 7) % 7;
+            const int ho = hi - R + 3;
+            if (ho >= h0 && ho < h1) {
+#pragma unroll
+              for (int sx = 0; sx < 7; ++sx) {                 // tap outer, output inner: seven independent accumulators in a row
+                f32x2 wt;
+                if constexpr (R < 6) wt = wv[R * 7 + sx];
+                else wt = w6[sx][threadIdx.x];
+#pragma unroll
+                for (int o = 0; o < 7; ++o) acc[SLOT][o] = __builtin_elementwise_fma(xu[o + sx], wt, acc[SLOT][o]);
+              }
+            }
+          });
+        }
+        const int ho = hi - 3;                               // complete: its last input row (kernel row 6) was hi
+        if (ho >= h0) {
+          constexpr int SLOT = (K + 4) % 7;
+          const unsigned int orow = yo + (unsigned)ho * rowb;
+#pragma unroll
+          for (int o = 0; o < 7; ++o)
+            if (w0 + o < W) *(unsigned int*)(yB + (orow + (unsigned)o * cb)) = pack_bf16x2(acc[SLOT][o][0], acc[SLOT][o][1]);
+          init_slot(std::integral_constant<int, SLOT>{}, ho + 7);
+        }
+      }
+    });
+  }
+}
+
+// Weight gradient in the same form: dw[r][s][c] = sum dy[n,h,w,c] * x[n,h+r-3,w+s-3,c].  A thread owns two channels of a
+// 7-column strip of one image and walks down it: input row h of x meets dy row h - r + 3 for every kernel row r.  The tap
+// accumulators (7 packed pairs per kernel row) and a ring of the dy rows in reach stay in registers; with all seven kernel
+// rows at once that is 98 + 98 VGPRs + the unpacked x row, which hipcc does not fit into 256 (hundreds of spills), so the walk
+// is done TWICE -- kernel rows 0..3, then 4..6 -- each pass with its own ring (4 / 3 dy rows): 196 / 147 v_pk_fma_f32 per 13
+// + 7 loads; the second read of x comes from L2.  The threads of a workgroup that hold the same channel pair are summed
+// through LDS in a fixed order; one partial [49][C] row per workgroup, folded by the slab reducer.
+template <int R0, int NR>
+__device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ xB, const unsigned char* __restrict__ dB,
+                                              float* __restrict__ part, float* red, bool active, unsigned int xo, unsigned int dyo,
+                                              unsigned int cb, unsigned int rowb, unsigned int colmask, int w0, int H, int W, int C,
+                                              int cpr_wg, int groups, int cslice, long long ib) {
+  const int tid = threadIdx.x;
+  f32x2 acc[NR * 7];
+#pragma unroll
+  for (int k = 0; k < NR * 7; ++k) acc[k] = f32x2{0.f, 0.f};
+  if (active) {
+    f32x2 dr[NR][7];                                         // ring: dy row hd lives in slot hd mod NR
+    auto load_dy = [&](auto slotc, int hd) {
+      constexpr int S = decltype(slotc)::value;
+      const unsigned int ro = dyo + (unsigned)hd * rowb;
+#pragma unroll
+      for (int o = 0; o < 7; ++o) {
+        const unsigned int v = (hd >= 0 && hd < H && w0 + o < W) ? *(const unsigned int*)(dB + (ro + (unsigned)o * cb)) : 0u;
+        dr[S][o] = f32x2{bf16_lo(v), bf16_hi(v)};
+      }
+    };
+    // what x row 0 needs besides the row it loads itself: dy rows 4 - R0 - NR .. 2 - R0 (zeros where outside the image)
+    static_for<0, NR - 1>([&](auto ic) {
+      constexpr int HD = 4 - R0 - NR + decltype(ic)::value;
+      load_dy(std::integral_constant<int, ((HD % NR) + NR) % NR>{}, HD);
+    });
+    for (int base = 0; base < H; base += NR) {
+      static_for<0, NR>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;               // = h mod NR
+        const int h = base + K;
+        if (h < H) {
+          load_dy(std::integral_constant<int, (((K - R0 + 3) % NR) + NR) % NR>{}, h - R0 + 3);   // the newest row in reach
+          const unsigned int ro = xo + (unsigned)h * rowb;
+          f32x2 xu[13];
+#pragma unroll
+          for (int j = 0; j < 13; ++j) {
+            const unsigned int raw = ((colmask >> j) & 1u) ? *(const unsigned int*)(xB + (ro + (unsigned)j * cb)) : 0u;
+            xu[j] = f32x2{bf16_lo(raw), bf16_hi(raw)};
+          }
+          static_for<0, NR>([&](auto rc) {
+            constexpr int RR = decltype(rc)::value;          // kernel row R0 + RR: dy row h - (R0 + RR) + 3 (zeros if outside)
+            constexpr int SLOT = (((K - (R0 + RR) + 3) % NR) + NR) % NR;
+#pragma unroll
+            for (int o = 0; o < 7; ++o)                        // seven independent accumulators (taps) per output column
+#pragma unroll
+              for (int sx = 0; sx < 7; ++sx)
+                acc[RR * 7 + sx] = __builtin_elementwise_fma(dr[SLOT][o], xu[o + sx], acc[RR * 7 + sx]);
+          });
+        }
+      });
+    }
+  }
+  // sum the `groups` threads that share a channel pair (fixed order): one kernel row of taps per pass through LDS
+  static_for<0, NR>([&](auto rc) {
+    constexpr int RR = decltype(rc)::value;
+    __syncthreads();
+#pragma unroll
+    for (int sx = 0; sx < 7; ++sx) {
+      red[(sx * 2 + 0) * 256 + tid] = acc[RR * 7 + sx][0];
+      red[(sx * 2 + 1) * 256 + tid] = acc[RR * 7 + sx][1];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 7 * 2 * cpr_wg; idx += 256) {
+      const int k2 = idx / cpr_wg, l = idx - k2 * cpr_wg;   // k2 = tap-in-row * 2 + (channel of the pair)
+      float sum = 0.f;
+      for (int g = 0; g < groups; ++g) sum += red[k2 * 256 + g * cpr_wg + l];
+      part[((long long)ib * 49 + (R0 + RR) * 7 + (k2 >> 1)) * C + (cslice * cpr_wg + l) * 2 + (k2 & 1)] = sum;
+    }
+  });
+}
+
+__global__ __launch_bounds__(256, 2) void dwconv7_wgrad_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                    float* __restrict__ part, int N, int H, int W, int C,
+                                                                    int nstrips, int groups) {
+  // workgroup = `groups` (n, strip) items x cpr_wg channel pairs, cpr_wg * groups == 256; blockIdx.x = cslice + nslices * item_block
+  __shared__ float red[7 * 2 * 256];   // one kernel row of taps at a time (14 KB)
+  const int cpr = C >> 1;
+  const int cpr_wg = 256 / groups;
+  const int nslices = cpr / cpr_wg;
+  const int cslice = blockIdx.x % nslices;
+  const long long ib = blockIdx.x / nslices;
+  const int tid = threadIdx.x;
+  const int cpl = tid % cpr_wg, grp = tid / cpr_wg;
+  const int c = (cslice * cpr_wg + cpl) * 2;
+  const long long item = ib * groups + grp;                 // (n, strip)
+  const bool active = item < (long long)N * nstrips;
+  const int strip = active ? (int)(item % nstrips) : 0, n = active ? (int)(item / nstrips) : 0;
+  const int w0 = strip * 7;
+  unsigned int colmask = 0;
+#pragma unroll
+  for (int j = 0; j < 13; ++j) colmask |= ((unsigned)(w0 - 3 + j) < (unsigned)W ? 1u : 0u) << j;
+  const unsigned int cb = (unsigned)C * 2u, rowb = (unsigned)W * cb;
+  const unsigned int img = (unsigned)n * (unsigned)H * rowb;
+  const unsigned int xo = img + (unsigned)(w0 - 3) * cb + (unsigned)c * 2u;
+  const unsigned int dyo = img + (unsigned)w0 * cb + (unsigned)c * 2u;
+  dw_wgrad_pass<0, 4>((const unsigned char*)x, (const unsigned char*)dy, part, red, active, xo, dyo, cb, rowb, colmask, w0, H, W, C,
+                      cpr_wg, groups, cslice, ib);
+  dw_wgrad_pass<4, 3>((const unsigned char*)x, (const unsigned char*)dy, part, red, active, xo, dyo, cb, rowb, colmask, w0, H, W, C,
+                      cpr_wg, groups, cslice, ib);
+}
+
 // out = inp + keep[b] * gamma[c] * z      (rows_per_image rows of C channels per sample; keep may be NULL)
 __global__ __launch_bounds__(256) void layerscale_fwd_kernel(const bf16_t* __restrict__ z, const bf16_t* __restrict__ inp,
                                                              const float* __restrict__ gamma, const float* __restrict__ keep,
@@ -252,9 +486,38 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const bf16_t* __res
 
 }  // namespace
 
+static int dw_rows_mode() {   // ICAMD_DWCONV_ROWS=0: the LDS tile kernels of round 1/2 (tests compare both)
+  static const int m = [] { const char* e = getenv("ICAMD_DWCONV_ROWS"); return e ? atoi(e) : 1; }();
+  return m;
+}
+
 int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* addend, bf16_t* y, int N, int H,
                          int W, int C, int flip, hipStream_t s) {
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
+  if (dw_rows_mode() && (long long)N * H * W * C * 2 < (1ll << 32)) {
+    const int nstrips = (W + 6) / 7;
+    // threads = channel pairs x strips x images: 98 304 = 1 536 waves on every ConvNeXt-T stage at batch 256; 246 VGPRs
+    // allow two waves per SIMD.  The image rows are cut in two from 28 rows up (6 halo rows are re-read per part; measured
+    // at batch 256: 56 x 56 x 96 forward 151 -> 137 us, 28 x 28 x 192 68 -> 61; 14 x 14 and 7 x 7 lose), and further while
+    // the grid would leave most of the chip idle.  The kernel is bound by the latency of its row loads (one row of lead:
+    // 13 dwords in flight per lane), not by its 343 v_pk_fma_f32 per row: 2.3-2.5 TB/s.
+    const long long per_part = (long long)(C / 2) * nstrips * N;
+    int hsplit = H >= 28 ? 2 : 1;
+    while (per_part * hsplit < 1536ll * 64 / 2 && H / (hsplit * 2) >= 7) hsplit *= 2;
+    static const int force = [] { const char* e = getenv("ICAMD_DW_HSPLIT"); return e ? atoi(e) : 0; }();
+    if (force > 0) hsplit = force;
+    const long long blocks = (per_part + 255) / 256;
+    if (blocks <= 0 || blocks >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
+    const unsigned int last_off = (unsigned int)((long long)N * H * W * C * 2 - 4);
+    const dim3 grid((unsigned)blocks, (unsigned)hsplit);
+    if (addend != nullptr)
+      hipLaunchKernelGGL(dwconv7_rows_kernel<true>, grid, dim3(256), 0, s, x, w, bias, addend, y, N, H, W, C, flip, nstrips,
+                         hsplit, (unsigned)per_part, last_off);
+    else
+      hipLaunchKernelGGL(dwconv7_rows_kernel<false>, grid, dim3(256), 0, s, x, w, bias, addend, y, N, H, W, C, flip, nstrips,
+                         hsplit, (unsigned)per_part, last_off);
+    return icamd_launch_status();
+  }
   // strips of 7 outputs per row and workgroup: as many as the row needs, up to 8 (TR = 64 / NS global rows each)
   const int ns = W <= 7 ? 1 : (W <= 14 ? 2 : (W <= 28 ? 4 : 8));
   const long long rows = (long long)N * H;
@@ -268,7 +531,26 @@ int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, co
   return icamd_launch_status();
 }
 
+// rows form: workgroup = 256 threads = groups x (256 / groups) channel pairs; groups = 256 / min(C/2, 256) so that a
+// workgroup's lanes cover whole pixels' channel runs where C/2 < 256 (C/2 must then divide 256: 16, 32, 64, 128, 256) --
+// else (C/2 = 48, 96, 192, 384: ConvNeXt's dims) the largest power-of-two slice that divides C/2
+static void dw_wgrad_rows_geometry(int N, int W, int C, int* nstrips, int* groups, int* nslices, long long* iblocks) {
+  const int cpr = C / 2;
+  int slice = 256;
+  while (cpr % slice != 0) slice >>= 1;            // C % 32 == 0  =>  slice >= 16
+  *groups = 256 / slice;
+  *nslices = cpr / slice;
+  *nstrips = (W + 6) / 7;
+  const long long items = (long long)N * *nstrips;
+  *iblocks = (items + *groups - 1) / *groups;
+}
+
 int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C) {
+  if (dw_rows_mode()) {
+    int nstrips, groups, nslices; long long ib;
+    dw_wgrad_rows_geometry(N, W, C, &nstrips, &groups, &nslices, &ib);
+    return (int)ib;
+  }
   const long long tiles = (long long)N * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
   long long nb = 1024 / (C / CG);
   if (nb < 1) nb = 1;
@@ -279,6 +561,16 @@ int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C) {
 int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, int N, int H, int W, int C,
                                int accumulate, hipStream_t s) {
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
+  if (dw_rows_mode()) {
+    int nstrips, groups, nslices; long long ib;
+    dw_wgrad_rows_geometry(N, W, C, &nstrips, &groups, &nslices, &ib);
+    if (ib * nslices >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dwconv7_wgrad_rows_kernel, dim3((unsigned)(ib * nslices)), dim3(256), 0, s, x, dy, part, N, H, W, C,
+                       nstrips, groups);
+    int rc = icamd_launch_status();
+    if (rc) return rc;
+    return icamd_slab_reduce_launch(part, dw, 49ll * C, (int)ib, accumulate, s);
+  }
   const int nb = icamd_dwconv7_wgrad_blocks(N, H, W, C);
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((unsigned)(nb * (C / CG))), dim3(256), 0, s, x, dy, part, N, H, W, C, nb);
   // fold the nb partial rows with the slab reducer (many workgroups, fixed order) -- 49*C is a multiple of 4

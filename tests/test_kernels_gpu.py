@@ -1307,7 +1307,9 @@ def test_attention_fwd_bwd(lib, B, T, H):
 
 
 @pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96), (3, 28, 28, 64),
-                                   (2, 11, 30, 32), (70, 3, 5, 32)])
+                                   (2, 11, 30, 32), (70, 3, 5, 32),
+                                   # rows split in two (H >= 28) with H odd, W not a multiple of 7, > 256 channel pairs per pixel
+                                   (2, 29, 31, 96), (5, 9, 8, 384), (1, 1, 1, 64), (3, 33, 6, 160)])
 def test_dwconv7_fwd_dgrad_wgrad(lib, shape):
     hip = _hip()
     N, H, W, C = shape
@@ -1338,6 +1340,18 @@ def test_dwconv7_fwd_dgrad_wgrad(lib, shape):
     sync()
     assert R.rel_l2(dx.float().cpu(), rdx) <= 1e-3 and R.bf16_close(dx.float().cpu(), rdx)
     assert R.rel_l2(dw.cpu(), 1.0 + rdw.permute(1, 2, 0)) <= 1e-4
+
+
+def test_dwconv7_lds_tile_form():
+    """ICAMD_DWCONV_ROWS=0: the LDS-tile kernels of rounds 1-2 (the default is the register sliding-window form) through the
+    same cases (child process: the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, ICAMD_DWCONV_ROWS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "test_dwconv7_fwd_dgrad_wgrad"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("use_keep", [False, True])
