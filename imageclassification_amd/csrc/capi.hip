@@ -186,6 +186,15 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
     return icamd_pw_resident_launch(g, (hipStream_t)stream);
   }
+  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && addend == nullptr && !relu && stats == nullptr &&
+      icamd_pw_resident_ext_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
+    PwResidentParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.bias = bias;
+    g.gelu_out = (bf16_t*)gelu_out; g.gelu_inplace = gelu_inplace;
+    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
+    return icamd_pw_resident_ext_launch(g, (hipStream_t)stream);
+  }
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 &&
       icamd_gemm_nt_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
     GemmNtParams g;
@@ -265,6 +274,14 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
     g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout;
     if (addend_sub2) { g.sub2_h = d->IH; g.sub2_w = d->IW; }
     return icamd_pw_resident_launch(g, (hipStream_t)stream);
+  }
+  if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && f == nullptr && addend == nullptr &&
+      icamd_pw_resident_ext_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {
+    PwResidentParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)dy; g.B = (const bf16_t*)w_t; g.out = (bf16_t*)dx; g.gelu_z = (const bf16_t*)gelu_z;
+    g.M = d->N * d->IH * d->IW; g.N = d->Cin; g.K = d->Cout;
+    return icamd_pw_resident_ext_launch(g, (hipStream_t)stream);
   }
   if (d->KH == 1 && d->KW == 1 && st == 1 && d->pad == 0 && f == nullptr && !(addend_bits != nullptr && addend_sub2) &&
       icamd_gemm_nt_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout)) {

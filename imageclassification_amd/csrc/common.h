@@ -71,10 +71,29 @@ static inline FastDiv make_fastdiv(unsigned int d) {
   return f;
 }
 
-// exact (erf) GELU and its derivative, as torch.nn.GELU() / timm's Mlp use
-__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+// GELU (erf form, as torch.nn.GELU() / timm's Mlp use) and its derivative.  gelu(z) = z * Phi(z), 2 Phi(z) = erfc(-z / sqrt 2).
+// erfc through Abramowitz & Stegun 7.1.26 (erfc(x) = (a1 t + .. + a5 t^5) e^{-x^2}, t = 1 / (1 + p x), x >= 0; |error| <= 1.5e-7):
+// one v_rcp_f32, one v_exp_f32 and ten multiply-adds, against the ~50 instructions of the device library's erff -- which made
+// the GELU epilogues VALU-bound: ConvNeXt-T evaluates 6.6 G of them per step (fc1 forward twice under mixup, fc2 data
+// gradient), ViT-B/16 3.7 G; the 96 -> 384 forward at batch 256 ran 527 us against 220 us of HBM time.  The negative side uses
+// erfc directly (no 1 - erf cancellation); measured against fp64 over all bf16 inputs in [-9, 9]: |gelu error| <= 4.6e-7,
+// |gelu' error| <= 3.1e-7 -- three orders below the bf16 rounding of the result.
+struct GeluParts { float cdf2, e; };   // 2 Phi(z), exp(-z^2 / 2)
+__device__ __forceinline__ GeluParts gelu_parts(float z) {
+  const float x = fabsf(z) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-x * x);
+  const float q = p * t * e;                       // erfc(|z| / sqrt 2)
+  return {z < 0.f ? q : 2.f - q, e};
+}
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * gelu_parts(z).cdf2; }
 __device__ __forceinline__ float gelu_grad_f(float z) {
-  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+  const GeluParts g = gelu_parts(z);
+  return fmaf(z * 0.39894228040143268f, g.e, 0.5f * g.cdf2);
 }
 // 8 bf16 values at once: a = gelu(z);  dz = da * gelu'(z)
 __device__ __forceinline__ u32x4 gelu8(const u32x4 z) {

@@ -28,7 +28,8 @@ namespace {
 
 // KS: k-steps of 32 (K = 32*KS); NF: 16-channel fragments per wave; MF: 16-row fragments per wave; WN: waves across the
 // channels (4 / WN across the rows); ADD: addend epilogue compiled in.
-template <int KS, int NF, int MF, int WN, bool ADD>
+// EXT: bias, GELU epilogues, a row pitch different from K and zero-extended filter columns (K = 96 run as KS = 4).
+template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
@@ -72,6 +73,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
       const int chunk = pos ^ sw(row);
       const int m = m0 + row;
       const bf16_t* src = m < m_end ? p.A + ((long long)m * p.K + chunk * 8) : zero;
+      if constexpr (EXT) {
+        // columns >= Ktrue of a row are the first columns of the NEXT row (multiplied by zero filter columns): real memory
+        // except behind the very last row
+        src = (m < m_end && (chunk * 8 < p.Ktrue || m + 1 < p.M)) ? p.A + ((long long)m * p.lda + chunk * 8) : zero;
+      }
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, 0);
     }
   };
@@ -83,7 +89,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int j = 0; j < NF; ++j) wf[ks][j] = *(const bf16x8*)(p.B + (long long)(n0 + j * 16 + fr) * p.K + ks * 32 + fq * 8);
+    for (int j = 0; j < NF; ++j) {
+      if constexpr (EXT) {
+        const int k = ks * 32 + fq * 8;
+        wf[ks][j] = k < p.Ktrue ? *(const bf16x8*)(p.B + (long long)(n0 + j * 16 + fr) * p.Ktrue + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      } else {
+        wf[ks][j] = *(const bf16x8*)(p.B + (long long)(n0 + j * 16 + fr) * p.K + ks * 32 + fq * 8);
+      }
+    }
   // arrived before the loop (the builtin: hipcc's wait-count bookkeeping sees it); also covers the first tile
   __builtin_amdgcn_s_waitcnt(0x0F70);
 
@@ -103,6 +116,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
+  f32x4 bias4[EXT ? NF : 1];      // MFMA layout: a lane owns channels n0 + j*16 + 4*fq .. +3 of its rows
+  if constexpr (EXT) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+      bias4[j] = p.bias != nullptr ? *(const f32x4*)(p.bias + n0 + j * 16 + 4 * fq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const bool want_stats = !ADD && p.stats != nullptr;   // the launcher never pairs statistics with an addend
 
   constexpr int STORES = MF * (EROW / 64);       // row-store instructions per wave and tile
@@ -181,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
 #pragma unroll
           for (int j = 0; j < NF; ++j) {
             f32x4 v = acc[j][i];
+            if constexpr (EXT) v += bias4[j];
             if constexpr (ADD) {
               if (has_add) {
                 constexpr int LPRA = EROW / 16;
@@ -211,9 +231,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
         if (i < MF) {
           const int rr = prow & 15, c = lane % LPR;
           const int ch = NF == 4 ? ((c ^ rr) & 7) : ((c ^ (rr >> 2)) & 3);
-          const u32x4 o = *(const u32x4*)(sE + prow * EROW + (ch << 4));
+          u32x4 o = *(const u32x4*)(sE + prow * EROW + (ch << 4));
           const int m = mw + i * 16 + rr;
           if (m < m_end) {
+            if constexpr (EXT) {
+              const long long off = (long long)m * p.N + n0 + c * 8;
+              if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
+              if (p.gelu_inplace) o = gelu8(o);
+              if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
+            }
             *(u32x4*)(p.out + (long long)m * p.N + n0 + c * 8) = o;
             if constexpr (!ADD) {
               if (want_stats) {
@@ -309,6 +335,31 @@ int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+// ConvNeXt-T's dim-96 Linear layers (96 -> 384 forward, and the data gradient of 384 -> 96): K = 96 is not a multiple of the
+// 64-wide stages of conv_igemm / gemm_nt and ran on conv_igemm's general-channel path at 391 us per launch at batch 256
+// (M = 802 816; 0.77-1.4 GB of HBM traffic: 120-220 us).  Here it is four 32-wide k-steps over 256 B staged rows.
+bool icamd_pw_resident_ext_wanted(long long M, int N, int K) {
+  return mode() != 0 && K == 96 && N % 128 == 0 && M >= 8192 && M < (1ll << 30);
+}
+
+int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
+  if (!icamd_pw_resident_ext_wanted(p.M, p.N, p.K) || p.addend != nullptr || p.stats != nullptr) return ICAMD_ERR_UNSUPPORTED;
+  p.lda = p.K; p.Ktrue = p.K; p.K = 128;
+  constexpr int tm = 64;                         // <4, 2, 4, 4>: 64 rows x 128 channels per workgroup
+  p.ntiles_n = p.N / 128;
+  const int wgs = 2 * icamd_num_cus();
+  int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
+  const int cap_tiles = (p.M + tm - 1) / tm;
+  if (S > cap_tiles) S = cap_tiles;
+  if (S < 1) S = 1;
+  int rows = (p.M + S - 1) / S;
+  rows = (rows + tm - 1) / tm * tm;
+  p.rows_per_split = rows;
+  S = (p.M + rows - 1) / rows;
+  hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
+  return icamd_launch_status();
+}
 
 bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend) {
   Config c;

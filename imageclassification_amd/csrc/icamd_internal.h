@@ -90,9 +90,19 @@ struct PwResidentParams {
   int sub2_h, sub2_w;    // > 0: addend is [.][ceil(h/2)][ceil(w/2)][N], added at even (h, w)
   FastDiv divHW, divW;   // filled by the launcher
   int rows_per_split, ntiles_n;   // filled by the launcher
+  // "ext" launches (ConvNeXt's dim-96 Linear layers: K = 96 runs as four 32-wide k-steps, the last one against zero filter
+  // columns): A rows are lda elements apart and only Ktrue of the K = 128 staged columns are real
+  int lda, Ktrue;                 // 0: K
+  const float* bias;              // optional [N]
+  bf16_t* gelu_out;               // optional second output: gelu(rounded out)
+  int gelu_inplace;               // out itself receives gelu(rounded result)
+  const bf16_t* gelu_z;           // optional [M][N]: out = rounded result * gelu'(gelu_z)
 };
 bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend = false);
+// the ext form: plain pointwise problems with K = 96 (bias / GELU epilogues allowed, no addend / statistics)
+bool icamd_pw_resident_ext_wanted(long long M, int N, int K);
 int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream);
+int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream);
 
 // ResNet stem forward with the filter resident in registers (conv_stem.hip)
 struct StemParams {

@@ -307,7 +307,11 @@ def test_conv_fwd_act_and_bn_fold(lib, case):
         assert R.rel_l2(got, full) <= 1e-2
 
 
-@pytest.mark.parametrize("case", [(2, 8, 8, 96, 384), (1, 20, 20, 192, 768), (4, 64, 64, 256, 1024)])
+@pytest.mark.parametrize("case", [(2, 8, 8, 96, 384), (1, 20, 20, 192, 768), (4, 64, 64, 256, 1024),
+                                  # ConvNeXt-T's dim-96 Linear layers on the register-resident kernel's K = 96 form (four k-steps
+                                  # over 256 B staged rows, zero filter columns; csrc/conv1x1_resident.hip EXT): forward of
+                                  # 96 -> 384 and data gradient of 384 -> 96, ragged last tile
+                                  (8, 40, 41, 96, 384), (8, 40, 41, 384, 96)])
 def test_pointwise_gelu_epilogues(lib, case):
     """fc1 forward with GELU in the store pass and fc2 data gradient with the GELU backward in the store pass are
     bit-identical to the two-kernel sequences they replace (and those are oracle-checked elsewhere); both GEMM kernels
@@ -329,6 +333,8 @@ def test_pointwise_gelu_epilogues(lib, case):
     assert lib.icamd_conv2d_fwd_gelu(ctypes.byref(d), hip.ptr(x), hip.ptr(wd), None, hip.ptr(a3), hip.ptr(bias), s) == 0
     sync()
     assert torch.equal(z1, z2) and torch.equal(a1, a2) and torch.equal(a1, a3)
+    ref_z = R.conv2d_fwd(x.float().cpu(), w, 1, 0, bias.cpu(), None)
+    assert R.rel_l2(z1.float().cpu(), ref_z) <= 1e-3 and R.bf16_close(z1.float().cpu(), ref_z)
     ref_a = R.bf16_round(torch.nn.functional.gelu(z1.float().cpu()))
     assert R.rel_l2(a2.float().cpu(), ref_a) <= 1e-3
     # backward of the layer that consumes `a`: d z = (dy W) * gelu'(z), here with this layer's shapes transposed
@@ -342,6 +348,8 @@ def test_pointwise_gelu_epilogues(lib, case):
     assert lib.icamd_conv2d_dgrad_gelu(ctypes.byref(d), hip.ptr(dy), hip.ptr(w_t), hip.ptr(zin), hip.ptr(dz2), s) == 0
     sync()
     assert torch.equal(dz1, dz2)
+    ref_da = R.conv2d_dgrad(dy.float().cpu(), w, (H, W), 1, 0, None)
+    assert R.rel_l2(da.float().cpu(), ref_da) <= 1e-3 and R.bf16_close(da.float().cpu(), ref_da)
 
 
 HALO_CASES = [  # N, H, W, C, Cout: 3x3 stride 1 pad 1 layers routed to csrc/conv3x3_halo.hip
@@ -1266,6 +1274,23 @@ def test_gelu_and_colsum_rows(lib):
     sync()
     rdz = R.gelu_bwd(da, z)
     assert R.rel_l2(dz.float().cpu(), rdz) <= 1e-3 and R.bf16_close(dz.float().cpu(), rdz)
+    # the kernels evaluate erfc by Abramowitz & Stegun 7.1.26 (csrc/common.h gelu_parts) instead of the library erff: EVERY
+    # bf16 input in [-9, 9] (both tails, where 1 + erf cancels) against the fp64 definition: the stored bf16 result is within
+    # one bf16 ulp of the exact value + 1e-6 absolute (the formula's own error is <= 5e-7)
+    allz = torch.arange(-2 ** 15, 2 ** 15, dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float()
+    allz = allz[torch.isfinite(allz) & (allz.abs() <= 9.0)]
+    allz = torch.cat([allz, torch.zeros((-allz.numel()) % 8)])
+    azd = to_dev_bf16(allz)
+    ga, gd = torch.empty_like(azd), torch.empty_like(azd)
+    ones = to_dev_bf16(torch.ones_like(allz))
+    assert lib.icamd_gelu_fwd(hip.ptr(azd), hip.ptr(ga), allz.numel(), hip.stream_ptr()) == 0
+    assert lib.icamd_gelu_bwd(hip.ptr(ones), hip.ptr(azd), hip.ptr(gd), allz.numel(), hip.stream_ptr()) == 0
+    sync()
+    zz = allz.double()
+    cdf = 0.5 * (1.0 + torch.erf(zz / 2 ** 0.5))
+    for got, exact in ((ga, zz * cdf), (gd, cdf + zz * torch.exp(-0.5 * zz * zz) / (2 * 3.141592653589793) ** 0.5)):
+        err = (got.float().cpu().double() - exact).abs()
+        assert bool((err <= exact.abs() * 2.0 ** -8 + 1e-6).all()), float(err.max())
     rows, ld, cols = 197 * 4, 3072, 3072
     wsb = lib.icamd_colsum_rows_workspace_bytes(rows, cols)
     ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
