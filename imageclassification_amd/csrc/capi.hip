@@ -27,7 +27,7 @@ int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, 
                              float* cA, float* partB, double* chunksB, float* cB, hipStream_t s);
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
                               const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
-                              long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s);
+                              long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s, int sums_are_gy = 0);
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s);
 int icamd_bn_relu_maxpool_fwd_launch(const bf16_t* y, const float* scale, const float* shift, bf16_t* out, unsigned char* idx,
@@ -387,6 +387,29 @@ int icamd_conv2d_dgrad_bnbwd(const icamd_conv_desc* d, const void* dy, const voi
   return dgrad_impl(d, dy, w_t, g, addend, nullptr, f, stream);
 }
 
+int icamd_conv2d_dgrad_bnred_supported(const icamd_conv_desc* d) {
+  if (!conv_desc_ok(d) || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0) return 0;
+  return icamd_pw_resident_bnred_wanted((long long)d->N * d->IH * d->IW, d->Cin, d->Cout) ? 1 : 0;
+}
+
+int icamd_conv2d_dgrad_bnred(const icamd_conv_desc* d, const void* dy, const void* w_t, void* g, const void* addend,
+                             const uint8_t* addend_bits, int addend_sub2, const void* bn_y, const uint8_t* bn_bits,
+                             float* partials, void* stream) {
+  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || g == nullptr || addend == nullptr || bn_y == nullptr ||
+      bn_bits == nullptr || partials == nullptr || (addend_sub2 && addend_bits != nullptr))
+    return ICAMD_ERR_BAD_ARG;
+  if (!icamd_conv2d_dgrad_bnred_supported(d)) return ICAMD_ERR_UNSUPPORTED;
+  PwResidentParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)dy; p.B = (const bf16_t*)w_t; p.out = (bf16_t*)g; p.addend = (const bf16_t*)addend;
+  p.addend_bits = addend_bits;
+  p.bn_y = (const bf16_t*)bn_y; p.bn_bits = bn_bits; p.bn_part = partials;
+  p.M = d->N * d->IH * d->IW; p.N = d->Cin; p.K = d->Cout;
+  if (addend_sub2) { p.sub2_h = d->IH; p.sub2_w = d->IW; }
+  return icamd_pw_resident_bnred_launch(p, (hipStream_t)stream);
+}
+
 size_t icamd_conv2d_wgrad_workspace_bytes(const icamd_conv_desc* d) {
   if (!conv_desc_ok(d)) return 0;
   int S = 1, rows = 0;
@@ -612,6 +635,24 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
   ws += bn_chunk_bytes(C);
   return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
                                    (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream);
+}
+
+int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* g, const void* y, const float* mean,
+                                  const float* invstd, const float* scale, float* dgamma, float* dbeta, void* dy,
+                                  long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  ProfScope _prof(PC_BN_BWD, stream);
+  if (partials == nullptr || nrows <= 0 || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr ||
+      scale == nullptr || dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 ||
+      C <= 0 || C % 8 != 0)
+    return ICAMD_ERR_BAD_ARG;
+  if (workspace_bytes < icamd_bn_bwd_apply_workspace_bytes(C)) return ICAMD_ERR_WORKSPACE;
+  if (C > 4096) return ICAMD_ERR_UNSUPPORTED;
+  char* ws = (char*)workspace;
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(C);
+  return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
+                                   (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream, 1);
 }
 
 // ---- LayerNorm / GELU / column sums (ViT, ConvNeXt) -------------------------------------------------------------

@@ -29,7 +29,13 @@ namespace {
 // KS: k-steps of 32 (K = 32*KS); NF: 16-channel fragments per wave; MF: 16-row fragments per wave; WN: waves across the
 // channels (4 / WN across the rows); ADD: addend epilogue compiled in.
 // EXT: bias, GELU epilogues, a row pitch different from K and zero-extended filter columns (K = 96 run as KS = 4).
-template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false>
+// BNR (with ADD): the output is g = the previous block's masked output gradient, and the pass-1 sums of that block's last
+// BatchNorm backward (sum g, sum g * xhat) are accumulated on the way out: the wave's sub-tile of the BatchNorm's input y comes
+// by LDS-DMA into a second wave-private patch at the START of the tile (exactly as the addend does: whole rows, no registers,
+// landing under the MFMAs), the mask words are one 64-bit load per row, and the store pass -- which already holds 8 channels
+// of one row per lane -- reads the matching 16 B of y back and keeps the sums in registers across tiles.  bn_bwd_reduce (a full
+// read of dout and y) disappears for that BatchNorm; this kernel reads y once instead.
+template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false, bool BNR = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
@@ -43,8 +49,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int IPW = NINST / 4;                // per wave
   static_assert(NINST % 4 == 0 && (NF == 2 || NF == 4) && KS >= 2 && KS <= 16, "configuration");
   constexpr int P_WAVE = ADD ? MF * 16 * EROW : 0;   // ADD: this wave's [MF*16 rows][CW] addend patch (LDS-DMA target)
-  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE <= 80 * 1024, "two workgroups per CU");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE];
+  constexpr int Y_WAVE = BNR ? MF * 16 * EROW : 0;   // BNR: the same shape for the BatchNorm input y
+  static_assert(!BNR || (ADD && NF == 4 && WN == 4 && !EXT), "bnred: 256-channel workgroups with an addend");
+  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     for (int j = 0; j < NF; ++j)
       bias4[j] = p.bias != nullptr ? *(const f32x4*)(p.bias + n0 + j * 16 + 4 * fq) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool want_stats = !ADD && p.stats != nullptr;   // the launcher never pairs statistics with an addend
+  const bool want_stats = BNR || (!ADD && p.stats != nullptr);   // the launcher never pairs statistics with an addend
 
   constexpr int STORES = MF * (EROW / 64);       // row-store instructions per wave and tile
   auto tile = [&](auto bufc, int tm0) {
@@ -137,8 +145,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     // page, so no mask is needed for them); the 1-bit masks of the wave's 16*NF channels are one word per row.
     const int mw = tm0 + wm * MF * 16;
     unsigned long long abw[ADD ? MF : 1];
+    unsigned long long pbw[BNR ? MF : 1];          // BNR: the previous block's ReLU mask words of this lane's rows
     bool has_add = false;
     unsigned char* const sP = smem + 2 * A_BYTES + 4 * E_WAVE + wave * P_WAVE;
+    unsigned char* const sY = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + wave * Y_WAVE;
     if constexpr (ADD) {
       has_add = true;
       constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;      // lanes per patch row, rows per instruction
@@ -162,6 +172,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           }
         }
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sP + q * 1024), 16, 0, 0);
+      }
+      if constexpr (BNR) {
+#pragma unroll
+        for (int q = 0; q < Y_WAVE / 1024; ++q) {
+          const int row = q * RPIA + lane / LPRA, pos = lane % LPRA;
+          const int chunk = pos ^ (row & (LPRA - 1));
+          const int m = mw + row;
+          const bf16_t* src = m < p.M ? p.bn_y + ((long long)m * p.N + n0 + chunk * 8) : zero;
+          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sY + q * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const int m = mw + i * 16 + fr;
+          pbw[i] = *(const unsigned long long*)(p.bn_bits + (((long long)(m < p.M ? m : 0) * p.N + n0) >> 3));
+        }
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
@@ -213,6 +238,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
                 v[3] += (bb & 8u) ? bf16_hi(a[1]) : 0.f;
               }
             }
+            if constexpr (BNR) {   // g = d(block output) * [block output > 0]
+              const unsigned int pb = (unsigned int)(pbw[i] >> (8 * (j * 2 + (fq >> 1)) + 4 * (fq & 1))) & 0xfu;
+              v[0] = (pb & 1u) ? v[0] : 0.f;
+              v[1] = (pb & 2u) ? v[1] : 0.f;
+              v[2] = (pb & 4u) ? v[2] : 0.f;
+              v[3] = (pb & 8u) ? v[3] : 0.f;
+            }
             u32x2 pk;
             pk[0] = pack_bf16x2(v[0], v[1]);
             pk[1] = pack_bf16x2(v[2], v[3]);
@@ -241,6 +273,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
               if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
             }
             *(u32x4*)(p.out + (long long)m * p.N + n0 + c * 8) = o;
+            if constexpr (BNR) {
+              const int pr = i * 16 + rr;                  // row of the wave's y patch; chunk c sits at c ^ (row & (LPR - 1))
+              const u32x4 yv = *(const u32x4*)(sY + pr * EROW + (((c ^ pr) & (LPR - 1)) << 4));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f32x2 g = {bf16_lo(o[e]), bf16_hi(o[e])};
+                const f32x2 yy = {bf16_lo(yv[e]), bf16_hi(yv[e])};
+                s1[e] += g;                                  // sum g and sum g * y: the finalize turns them into sum g * xhat
+                s2[e] = __builtin_elementwise_fma(g, yy, s2[e]);
+              }
+            }
             if constexpr (!ADD) {
               if (want_stats) {
 #pragma unroll
@@ -295,8 +338,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
 #pragma unroll 4
       for (int k = 0; k < WM * G; ++k) s += red[(k * 2 + which) * COLS + cc];
       const int col = tile_n * COLS + cc;
-      p.stats[((long long)split * 2 + which) * p.N + col] = s;
-      for (int r = split + S; r < nrows; r += S) p.stats[((long long)r * 2 + which) * p.N + col] = 0.f;
+      float* const table = BNR ? p.bn_part : p.stats;
+      table[((long long)split * 2 + which) * p.N + col] = s;
+      for (int r = split + S; r < nrows; r += S) table[((long long)r * 2 + which) * p.N + col] = 0.f;
     }
   }
 }
@@ -335,6 +379,43 @@ int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+// The residual data gradients of ResNet-50's identity blocks: (K, N) = (planes, 4 * planes) for layer1..layer3.  Half the row
+// fragments per tile of the plain kernel (MF = 2), so that the second patch fits the 80 KB of two workgroups per CU; layer4
+// (K = 512: 64 KB of activation buffers) does not fit and keeps the two-pass BatchNorm backward.
+bool icamd_pw_resident_bnred_wanted(long long M, int N, int K) {
+  static const int on = [] { const char* e = getenv("ICAMD_BNRED"); return e ? atoi(e) : 1; }();
+  if (!on || mode() == 0 || M < 8192 || M >= (1ll << 30) || N % 256 != 0) return false;
+  return K == 64 || K == 128 || K == 256;
+}
+
+int icamd_pw_resident_bnred_launch(PwResidentParams& p, hipStream_t stream) {
+  if (!icamd_pw_resident_bnred_wanted(p.M, p.N, p.K) || p.addend == nullptr || p.stats != nullptr ||
+      (p.sub2_h > 0 && p.addend_bits != nullptr) ||
+      p.bn_y == nullptr || p.bn_bits == nullptr || p.bn_part == nullptr)
+    return ICAMD_ERR_UNSUPPORTED;
+  constexpr int tm = 32;                         // WM = 1, MF = 2
+  p.ntiles_n = p.N / 256;
+  const int wgs = 2 * icamd_num_cus();
+  int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
+  const int cap_tiles = (p.M + tm - 1) / tm, cap_rows = (p.M + 127) / 128;
+  if (S > cap_tiles) S = cap_tiles;
+  if (S > cap_rows) S = cap_rows;                // one partial row per split in the [ceil(M/128)] table
+  if (S < 1) S = 1;
+  int rows = (p.M + S - 1) / S;
+  rows = (rows + tm - 1) / tm * tm;
+  p.rows_per_split = rows;
+  S = (p.M + rows - 1) / rows;
+  if (p.sub2_h > 0) {
+    p.divHW = make_fastdiv((unsigned)(p.sub2_h * p.sub2_w));
+    p.divW = make_fastdiv((unsigned)p.sub2_w);
+  }
+  const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
+  if (p.K == 64) hipLaunchKernelGGL((conv1x1_resident_kernel<2, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
+  else if (p.K == 128) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((conv1x1_resident_kernel<8, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
+  return icamd_launch_status();
+}
 
 // ConvNeXt-T's dim-96 Linear layers (96 -> 384 forward, and the data gradient of 384 -> 96): K = 96 is not a multiple of the
 // 64-wide stages of conv_igemm / gemm_nt and ran on conv_igemm's general-channel path at 391 us per launch at batch 256

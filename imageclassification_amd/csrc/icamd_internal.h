@@ -92,6 +92,13 @@ struct PwResidentParams {
   int rows_per_split, ntiles_n;   // filled by the launcher
   // "ext" launches (ConvNeXt's dim-96 Linear layers: K = 96 runs as four 32-wide k-steps, the last one against zero filter
   // columns): A rows are lda elements apart and only Ktrue of the K = 128 staged columns are real
+  // "bnred" launches (residual data gradient whose output is the output gradient of the PREVIOUS block's last BatchNorm):
+  // the epilogue gates the result with that block's ReLU mask bits, stores g and accumulates sum g and sum g * bn_y per
+  // channel into one partial row per workgroup of bn_part[ceil(M/128)][2][N] (other rows zero); the finalize forms
+  // sum g * xhat = invstd * (sum g*y - mean * sum g) in fp64
+  const bf16_t* bn_y;             // [M][N] raw conv output the BatchNorm normalised
+  const unsigned char* bn_bits;   // 1 bit per element: the block output was > 0
+  float* bn_part;
   int lda, Ktrue;                 // 0: K
   const float* bias;              // optional [N]
   bf16_t* gelu_out;               // optional second output: gelu(rounded out)
@@ -103,6 +110,9 @@ bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend = fals
 bool icamd_pw_resident_ext_wanted(long long M, int N, int K);
 int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream);
 int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream);
+// the bnred form: full-size addend (optionally gated by its own mask bits), (K, N) in {(64, 256), (128, 512), (256, 1024)}
+bool icamd_pw_resident_bnred_wanted(long long M, int N, int K);
+int icamd_pw_resident_bnred_launch(PwResidentParams& p, hipStream_t stream);
 
 // ResNet stem forward with the filter resident in registers (conv_stem.hip)
 struct StemParams {

@@ -37,6 +37,7 @@ struct BnFinalizeArgs {
   float* mean_out; float* invstd_out; float* scale_out; float* shift_out;
   // MODE 1 (backward sums)
   float* dgamma; float* dbeta; float* c1_out; float* c2_out; int accumulate;
+  const float* gy_mean; const float* gy_invstd;   // set: the second sum is sum g*y, turned into sum g*xhat here
   double count;
 };
 
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
       a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
     }
   } else {
+    if (a.gy_mean != nullptr) t2 = (double)a.gy_invstd[c] * (t2 - (double)a.gy_mean[c] * t1);
     a.c1_out[c] = (float)(t1 / a.count);
     a.c2_out[c] = (float)(t2 / a.count);
     if (a.accumulate) { a.dgamma[c] += (float)t2; a.dbeta[c] += (float)t1; }
@@ -949,7 +951,8 @@ int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, 
 // g is already masked, so the apply kernel runs without a ReLU mask; shift is unused in that mode.
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
                               const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
-                              long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s) {
+                              long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s,
+                              int sums_are_gy) {
   float* c1 = c1c2;
   float* c2 = c1c2 + C;
   int rc;
@@ -958,6 +961,7 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
     chunking(nrows, &rpc, &nc);
     BnFinalizeArgs a = {};
     a.dgamma = dgamma; a.dbeta = dbeta; a.c1_out = c1; a.c2_out = c2; a.accumulate = accumulate; a.count = (double)rows;
+    if (sums_are_gy) { a.gy_mean = mean; a.gy_invstd = invstd; }
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<1>, dim3((unsigned)((C + 63) / 64), (unsigned)nc), dim3(1024), 0, s, part,
                        chunks, counters_of(chunks, C), nrows, C, rpc, a);
     rc = icamd_launch_status();

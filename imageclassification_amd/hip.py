@@ -60,6 +60,9 @@ _SIGNATURES = {
     "icamd_conv2d_dgrad_sub2": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
     "icamd_conv2d_dgrad_stats_rows": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_dgrad_bnbwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, POINTER(BnBwdFuse), _P]),
+    "icamd_conv2d_dgrad_bnred_supported": (c_int, [POINTER(ConvDesc)]),
+    "icamd_conv2d_dgrad_bnred": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    "icamd_bn_bwd_from_gy_partials": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
     "icamd_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "icamd_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, c_size_t, _P]),
     "icamd_conv2d_wgrad_bias": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P]),

@@ -735,7 +735,12 @@ class ResNet(PicklableModel):
         dout, other = D0, D1
         hip.check(lib.icamd_avgpool_bwd(ws["dpooled"].data_ptr(), dout, N, fh * fw, self.feat_dim, s), "avgpool bwd")
 
-        for blk, b in zip(reversed(self.blocks), reversed(ws["blocks"])):
+        # Residual data gradients that ALSO do pass 1 of the previous block's last BatchNorm backward (icamd_conv2d_dgrad_bnred):
+        # `fused_rows` > 0 says `dout` already holds g = masked output gradient of the block about to be processed and
+        # ws["bnb_part"] its partial sums (sum g, sum g*y), so that block starts with the apply pass only
+        fused_rows = 0
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            blk, b = self.blocks[bi], ws["blocks"][bi]
             convs, bns = blk["convs"], blk["bns"]
             h, w = b["in_hw"]
             xin = b["in"]
@@ -763,8 +768,18 @@ class ResNet(PicklableModel):
                                                 stB + 4 * c, stB + 8 * c, self._gf(bnB.weight), self._gf(bnB.bias), ypool[y2],
                                                 b["y"][-1].numel() // c, c, acc, bws, ws["bnb_ws2"].data_ptr(), bwb, s),
                           bnA.name + " + shortcut bwd")
+            elif fused_rows:
+                bnl = bns[-1]
+                stl = self.stat_arena.data_ptr() + 4 * bnl.stat_offset
+                cl = bnl.c
+                hip.check(lib.icamd_bn_bwd_from_gy_partials(ws["bnb_part"].data_ptr(), fused_rows, dout, b["y"][-1].data_ptr(),
+                                                            stl, stl + 4 * cl, stl + 8 * cl, self._gf(bnl.weight),
+                                                            self._gf(bnl.bias), ypool[yk], b["y"][-1].numel() // cl, cl, acc,
+                                                            ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"], s),
+                          bnl.name + " bwd (apply, sums from the data gradient)")
             else:
                 bn_bwd(bns[-1], dout, None, b["y"][-1], ypool[yk], None, True, mask)
+            fused_rows = 0
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
                 # wgrad first: measured, it overlaps best with the data-gradient kernel of the same layer (issued after it,
@@ -793,13 +808,33 @@ class ResNet(PicklableModel):
                     hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d1), ypool[y2], self._wt(dc), T, None, None, s),
                               dc.name + " dgrad (even grid)")
                     d0 = convs[0].desc(N, h, w)
-                    hip.check(lib.icamd_conv2d_dgrad_sub2(ctypes.byref(d0), ypool[yk], self._wt(convs[0]), other, T, s),
-                              convs[0].name + " dgrad + shortcut")
+                    if (bi > 0 and "down_conv" not in self.blocks[bi - 1] and self.block == "bottleneck"
+                            and lib.icamd_conv2d_dgrad_bnred_supported(ctypes.byref(d0))):
+                        pb = ws["blocks"][bi - 1]   # (see the identity-shortcut case below)
+                        hip.check(lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d0), ypool[yk], self._wt(convs[0]), other, T, None, 1,
+                                                               pb["y"][-1].data_ptr(), pb["mask"].data_ptr(),
+                                                               ws["bnb_part"].data_ptr(), s),
+                                  convs[0].name + " dgrad + shortcut + bn reduce")
+                        fused_rows = lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d0))
+                    else:
+                        hip.check(lib.icamd_conv2d_dgrad_sub2(ctypes.byref(d0), ypool[yk], self._wt(convs[0]), other, T, s),
+                                  convs[0].name + " dgrad + shortcut")
                 else:
                     dgrad(dc, ypool[y2], T, None, N, h, w)
                     dgrad(convs[0], ypool[yk], other, T, N, h, w)
             else:
-                dgrad(convs[0], ypool[yk], other, dout, N, h, w, mask)
+                d0 = convs[0].desc(N, h, w)
+                if (bi > 0 and "down_conv" not in self.blocks[bi - 1] and self.block == "bottleneck"
+                        and lib.icamd_conv2d_dgrad_bnred_supported(ctypes.byref(d0))):
+                    # `other` becomes g of the previous block (its ReLU mask applied, which every consumer of d(block output)
+                    # applies anyway) and the sums its last BatchNorm's backward needs come out of the same launch
+                    pb = ws["blocks"][bi - 1]
+                    hip.check(lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d0), ypool[yk], self._wt(convs[0]), other, dout, mask, 0,
+                                                           pb["y"][-1].data_ptr(), pb["mask"].data_ptr(),
+                                                           ws["bnb_part"].data_ptr(), s), convs[0].name + " dgrad + bn reduce")
+                    fused_rows = lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d0))
+                else:
+                    dgrad(convs[0], ypool[yk], other, dout, N, h, w, mask)
             if hook:
                 hook(convs[0].w.offset, None, side_events())
             dout, other = other, dout

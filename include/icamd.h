@@ -175,6 +175,25 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
                                long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* The residual data gradient of a bottleneck's first 1x1 convolution produces d(previous block's output): fused form that
+ * also does pass 1 of THAT block's last BatchNorm backward (replaces the bn_bwd reduce pass: one full read of dout and y).
+ *   g = (dgrad(dy, w_t) + addend [gated by addend_bits]) gated by bn_bits (the previous block's ReLU mask, 1 bit / element);
+ *   addend_sub2 != 0: addend is [N][ceil(IH/2)][ceil(IW/2)][Cin], added at the even pixels (as icamd_conv2d_dgrad_sub2;
+ *   addend_bits must then be NULL)
+ *   partials float [icamd_conv2d_dgrad_stats_rows(d)][2][Cin]: per-workgroup sums of g and of g * bn_y (bn_y = the raw
+ *   convolution output that BatchNorm normalised); icamd_bn_bwd_from_gy_partials turns them into the BatchNorm gradients.
+ * _supported: 1 where the register-resident pointwise kernel has this form (1x1 / stride 1, Cout in {64, 128, 256},
+ * Cin % 256 == 0, >= 8192 pixels); elsewhere the caller keeps icamd_conv2d_dgrad + icamd_bn_bwd. */
+int icamd_conv2d_dgrad_bnred_supported(const icamd_conv_desc* d);
+int icamd_conv2d_dgrad_bnred(const icamd_conv_desc* d, const void* dy, const void* w_t, void* g, const void* addend,
+                             const uint8_t* addend_bits, int addend_sub2, const void* bn_y, const uint8_t* bn_bits,
+                             float* partials, void* stream);
+/* as icamd_bn_bwd_from_partials, the second partial sum being sum g*y: sum g*xhat = invstd * (sum g*y - mean * sum g) (fp64) */
+int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* g, const void* y, const float* mean,
+                                  const float* invstd, const float* scale, float* dgamma, float* dbeta, void* dy,
+                                  long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* ---- LayerNorm / GELU / long column sums (ViT and ConvNeXt layers of the same reference calls; LayerNorm spec
  *      /root/reference/semantic_segmentation/backbone/convnext.py:158-182, exact-erf GELU :37) ------------------- */
 /* y = (x - mean_C) * rstd * gamma + beta over the last dimension of x [rows][C] (C % 4 == 0, C <= 1024);

@@ -1177,6 +1177,90 @@ def test_conv_dgrad_addend_maskbits(lib):
                                   hip.stream_ptr()) == 1      # bits without an addend: bad argument
 
 
+@pytest.mark.parametrize("case", [(4, 48, 48, 256, 64), (3, 56, 56, 512, 128), (12, 28, 28, 1024, 256), (5, 41, 41, 256, 64)])
+def test_conv_dgrad_bnred(lib, case):
+    """icamd_conv2d_dgrad_bnred: the residual data gradient of a bottleneck's conv1 (Cin = 4 * planes <- Cout = planes) whose
+    output is d(previous block output): g = (dgrad + addend * [addend bit]) * [previous block's mask bit], plus the per-channel
+    sums of g and g*y that replace the first pass of that block's last BatchNorm backward -- against the oracle's two steps;
+    then icamd_bn_bwd_from_gy_partials against the oracle's BatchNorm backward on the same g.  Shapes = the three routed
+    (K, N) pairs; ragged last tile; also the kernel must refuse shapes it does not have."""
+    hip = _hip()
+    N, H, W, Cin, Cout = case
+    d = hip.conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0)
+    assert lib.icamd_conv2d_dgrad_bnred_supported(ctypes.byref(d)) == 1
+    M = N * H * W
+    gen = torch.Generator().manual_seed(140)
+    dy = rnd_bf16(N, H, W, Cout, seed=141)
+    w = rnd_bf16(Cout, 1, 1, Cin, scale=(1.0 / Cout) ** 0.5, seed=142)
+    addend = rnd_bf16(N, H, W, Cin, seed=143)
+    y = rnd_bf16(N, H, W, Cin, scale=1.5, seed=144) + 0.3          # the BatchNorm input, deliberately not zero-mean
+    y = R.bf16_round(y)
+    amask = torch.rand(N, H, W, Cin, generator=gen) > 0.4
+    pmask = torch.rand(N, H, W, Cin, generator=gen) > 0.45
+    pack = lambda m: (m.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)  # noqa: E731
+    dout = R.conv2d_dgrad(dy, w, (H, W), 1, 0, addend * amask)     # bf16-rounded d(block output)
+    # the kernel masks BEFORE its single rounding; a masked element is exactly zero either way
+    g_ref = dout * pmask
+    dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w.permute(3, 1, 2, 0).contiguous())
+    ad, yd, abits, pbits = to_dev_bf16(addend), to_dev_bf16(y), pack(amask).to(DEV), pack(pmask).to(DEV)
+    rows = lib.icamd_conv2d_dgrad_stats_rows(ctypes.byref(d))
+    assert rows == (M + 127) // 128
+    part = torch.full((rows, 2, Cin), float("nan"), device=DEV)
+    g = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+    s = hip.stream_ptr()
+    assert lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(g), hip.ptr(ad), hip.ptr(abits), 0,
+                                        hip.ptr(yd), hip.ptr(pbits), hip.ptr(part), s) == 0
+    sync()
+    got = g.float().cpu()
+    assert torch.isfinite(got).all() and R.rel_l2(got, g_ref) <= 1e-3 and R.bf16_close(got, g_ref)
+    assert bool((got[~pmask] == 0).all())
+    pt = part.double().cpu()
+    assert torch.isfinite(pt).all()
+    sg = got.double().reshape(-1, Cin).sum(0)
+    sgy = (got.double() * y.double()).reshape(-1, Cin).sum(0)
+    assert torch.allclose(pt[:, 0].sum(0), sg, rtol=1e-5, atol=1e-2) and torch.allclose(pt[:, 1].sum(0), sgy, rtol=1e-5, atol=1e-2)
+    # the apply half: BatchNorm backward from those sums == the oracle's BatchNorm backward of the same g
+    yy = y.double().reshape(-1, Cin)
+    mean, var = yy.mean(0), yy.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma = 0.5 + torch.rand(Cin, generator=gen)
+    scale = gamma * invstd.float()
+    ones = torch.ones_like(got)
+    rdy, rdgamma, rdbeta, _ = R.bn_bwd(got, ones, y, mean.float(), invstd.float(), scale)
+    md, isd, scd = mean.float().to(DEV), invstd.float().to(DEV), scale.to(DEV)
+    dgam, dbet = torch.zeros(Cin, device=DEV), torch.zeros(Cin, device=DEV)
+    dyo = torch.empty_like(g)
+    wsb = lib.icamd_bn_bwd_apply_workspace_bytes(Cin)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    assert lib.icamd_bn_bwd_from_gy_partials(hip.ptr(part), rows, hip.ptr(g), hip.ptr(yd), hip.ptr(md), hip.ptr(isd), hip.ptr(scd),
+                                             hip.ptr(dgam), hip.ptr(dbet), hip.ptr(dyo), M, Cin, 0, hip.ptr(ws), wsb, s) == 0
+    sync()
+    assert R.rel_l2(dyo.float().cpu(), rdy) <= 1e-3 and R.bf16_close(dyo.float().cpu(), rdy)
+    assert R.rel_l2(dgam.cpu(), rdgamma) <= 1e-4 and R.rel_l2(dbet.cpu(), rdbeta) <= 1e-4
+    # shapes without this form are refused (the caller keeps icamd_conv2d_dgrad + icamd_bn_bwd)
+    d2 = hip.conv_desc(2, 8, 8, 2048, 512, 1, 1, 1, 0)
+    assert lib.icamd_conv2d_dgrad_bnred_supported(ctypes.byref(d2)) == 0
+    assert lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d2), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(g), hip.ptr(ad), None, 0, hip.ptr(yd),
+                                        hip.ptr(pbits), hip.ptr(part), s) == 2
+    # the even-grid addend form (a projection block's 1x1 stride-2 shortcut gradient lives on the even pixels only)
+    compact = rnd_bf16(N, (H + 1) // 2, (W + 1) // 2, Cin, seed=145)
+    full = torch.zeros(N, H, W, Cin)
+    full[:, ::2, ::2, :] = compact
+    g2_ref = R.conv2d_dgrad(dy, w, (H, W), 1, 0, full) * pmask
+    cd = to_dev_bf16(compact)
+    part.fill_(float("nan"))
+    assert lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(g), hip.ptr(cd), None, 1,
+                                        hip.ptr(yd), hip.ptr(pbits), hip.ptr(part), s) == 0
+    sync()
+    got2 = g.float().cpu()
+    assert R.rel_l2(got2, g2_ref) <= 1e-3 and R.bf16_close(got2, g2_ref)
+    pt2 = part.double().cpu()
+    assert torch.allclose(pt2[:, 0].sum(0), got2.double().reshape(-1, Cin).sum(0), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(pt2[:, 1].sum(0), (got2.double() * y.double()).reshape(-1, Cin).sum(0), rtol=1e-5, atol=1e-2)
+    assert lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(g), hip.ptr(cd), hip.ptr(abits), 1,
+                                        hip.ptr(yd), hip.ptr(pbits), hip.ptr(part), s) == 1
+
+
 @pytest.mark.parametrize("case", [(2, 10, 9, 128, 64, 1, 1, 0), (2, 12, 12, 256, 128, 1, 1, 0), (2, 9, 11, 64, 64, 3, 2, 1),
                                   (1, 8, 8, 512, 256, 1, 1, 0)])
 def test_conv_dgrad_addend_on_even_grid(lib, case):
