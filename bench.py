@@ -40,15 +40,22 @@ def conv_flops_per_image(net, hw):
 
     h, w = add(net.stem_conv, h, w)
     h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    for blk in net.blocks:
+    dgrad_extra = 0   # bytes per image the data-gradient class moves beyond in + out + filter: the BatchNorm input y read by the
+                      # launches that carry the previous block's BatchNorm-backward reduction (icamd_conv2d_dgrad_bnred)
+    for bi, blk in enumerate(net.blocks):
         ih, iw = h, w
         if "down_conv" in blk:
             add(blk["down_conv"], h, w)
+        c1 = blk["convs"][0]
+        if (net.block == "bottleneck" and bi > 0 and "down_conv" not in net.blocks[bi - 1] and c1.k == 1 and c1.stride == 1
+                and c1.cout in (64, 128, 256) and c1.cin % 256 == 0):
+            dgrad_extra += 2 * h * w * c1.cin
         for conv in blk["convs"]:
             ih, iw = add(conv, ih, iw)
         h, w = ih, iw
     add(net.fc, 1, 1)
     conv_flops_per_image.layer_bytes = layer_bytes
+    conv_flops_per_image.dgrad_extra = dgrad_extra
     return layers
 
 
@@ -166,7 +173,7 @@ def main():
     ap.add_argument("--mixup", action="store_true", help="mixup 0.8 + cutmix 1.0 + EMA (BASELINE configs[4] recipe)")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=3)
-    ap.add_argument("--pmc-file", default="r02_pmc_traffic.json", help="PMC traffic summary under profiles/")
+    ap.add_argument("--pmc-file", default=None, help="PMC traffic summary under profiles/ (default: this round's file for --arch)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches resident in HBM (SURVEY 8d: K >= 8)")
     ap.add_argument("--transport", default=None, choices=["torch", "rccl"],
                     help="gradient transport at N > 1: torch.distributed's RCCL process group (default) or the library's own "
@@ -313,19 +320,33 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/): only used when
         # the summary was collected for THIS workload on THESE kernel sources (hash stamp), else null + a note
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(ROOT, "profiles", args.pmc_file)
+        pmc_file = args.pmc_file or {"resnet50": "r03_pmc_traffic.json", "vit_base_patch16_224": "r03_pmc_traffic_vit.json",
+                                     "convnext_tiny": "r03_pmc_traffic_convnext.json"}.get(args.arch, "r03_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", pmc_file)
+        # every kernel a C-ABI call of the class can launch (csrc/capi.hip routing), by name prefix.  The weight-gradient kernels
+        # serve that class only (its fp32 slab fold included); the forward and data-gradient calls share their kernels, so for
+        # those two classes the PMC bytes are averaged over the launches of BOTH (said in traffic_note).
+        wgrad_names = ("conv_wgrad_kernel", "conv_wgrad_ring_kernel", "conv3x3_wgrad_halo_kernel", "stem7x7s2_wgrad_resident_kernel",
+                       "slab_reduce_kernel")
+        fd_names = ("conv_igemm_kernel", "conv1x1_resident_kernel", "conv3x3_halo_kernel", "conv3x3_c64_resident_kernel",
+                    "stem7x7s2_resident_kernel", "gemm_nt_kernel", "gemm_nt_8phase_kernel", "attn_fwd_kernel", "attn_bwd")
         try:
             pmc = json.load(open(pmc_path))
             if pmc.get("workload", {}).get("arch") != args.arch or pmc.get("workload", {}).get("batch") != B:
-                traffic_note = f"{args.pmc_file} was collected for another workload"
+                traffic_note = f"{pmc_file} was collected for another workload"
             elif pmc.get("kernel_source_hash") != kernel_source_hash():
-                traffic_note = (f"stale: {args.pmc_file} was collected on kernel sources {pmc.get('kernel_source_hash')}, "
+                traffic_note = (f"stale: {pmc_file} was collected on kernel sources {pmc.get('kernel_source_hash')}, "
                                 f"this build is {kernel_source_hash()}")
             else:
-                names = {"conv_wgrad": "conv_wgrad_kernel", "conv_fwd": "conv_igemm_kernel", "conv_dgrad": "conv_igemm_kernel"}
-                sel = [v for k, v in pmc["kernels"].items() if k.startswith(names[dom])]
-                n = sum(v["launches"] for v in sel)
-                traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in sel) / n)
+                names = wgrad_names if dom == "conv_wgrad" else fd_names
+                sel = [v for k, v in pmc["kernels"].items() if k.startswith(names)]
+                per_step = sum(v["fetch_GB_per_step"] + v["write_GB_per_step"] for v in sel) * 1e9
+                calls = kern[dom]["calls_per_step"]
+                if dom != "conv_wgrad":
+                    calls = sum(kern[k]["calls_per_step"] for k in ("conv_fwd", "conv_dgrad") if k in kern)
+                    traffic_note = ("forward and data-gradient calls share their kernels: PMC bytes of those kernels averaged over "
+                                    "the launches of both classes")
+                traffic = round(per_step / calls)
         except (OSError, KeyError, ValueError, ZeroDivisionError) as e:
             traffic_note = f"no usable PMC summary ({type(e).__name__})"
         avg_us = round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2)
@@ -335,6 +356,23 @@ def main():
         if traffic_note:
             roofline["traffic_note"] = traffic_note
         lb = getattr(conv_flops_per_image, "layer_bytes", None)
+        roofline_classes = {}
+        if lb is not None:
+            # every MFMA class against both roofs (the `roofline` object below is the one of the class that takes the most time)
+            for cls in mfma_classes:
+                lbc = lb[1:] if cls == "conv_dgrad" else lb
+                passes_c = nfwd if cls == "conv_fwd" else 1
+                act_c = sum(i + o for i, o, _ in lbc) * B * passes_c
+                if cls == "conv_dgrad" and not (is_vit or is_cnx):
+                    act_c += getattr(conv_flops_per_image, "dgrad_extra", 0) * B
+                wts_c = sum(w_ for _, _, w_ in lbc) * (4 if cls == "conv_wgrad" else 2) * passes_c
+                sec = kern[cls]["ms_per_step"] * 1e-3
+                roofline_classes[cls] = {"ms_per_step": round(kern[cls]["ms_per_step"], 3),
+                                         "calls_per_step": kern[cls]["calls_per_step"],
+                                         "tflops": round(algo[cls] / sec / 1e12, 1),
+                                         "mfma_frac": round(algo[cls] / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                         "algorithmic_GB_per_step": round((act_c + wts_c) / 1e9, 3),
+                                         "hbm_frac": round((act_c + wts_c) / sec / 1e9 / PEAK_HBM_GBS, 4)}
         if lb is not None:
             # The same launches against the HBM roof: algorithmic bytes = each layer's input + output activations once
             # (bf16) + its filters (bf16 shadow read by fwd/dgrad; fp32 gradient written by wgrad).  ResNet's convolutions
@@ -344,6 +382,8 @@ def main():
                 lb = lb[1:]
             passes = nfwd if dom == "conv_fwd" else 1
             act = sum(i + o for i, o, _ in lb) * B * passes
+            if dom == "conv_dgrad" and not (is_vit or is_cnx):
+                act += getattr(conv_flops_per_image, "dgrad_extra", 0) * B
             wts = sum(w for _, _, w in lb) * (4 if dom == "conv_wgrad" else 2) * passes
             gbs = (act + wts) / (kern[dom]["ms_per_step"] * 1e-3) / 1e9
             roofline["mfma_frac"] = roofline["frac"]
@@ -378,7 +418,8 @@ def main():
                "config": {"workload": f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, "
                                       f"label smoothing 0.1, 1000 classes (BASELINE configs[{3 if is_vit else (4 if is_cnx else (1 if world == 1 else 2))}])",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
-               "n_ranks_seen": ranks_seen, "roofline": roofline, "cpu_baseline": cpu, "kernels": kern,
+               "n_ranks_seen": ranks_seen, "roofline": roofline, "roofline_classes": roofline_classes, "cpu_baseline": cpu,
+               "kernels": kern,
                "kernel_source_hash": kernel_source_hash(),
                "kernel_timing": {"method": "HIP events on the launch stream around every C-ABI call; separate single-stream pass "
                                            "(the timed region overlaps weight gradients on a second stream)",
