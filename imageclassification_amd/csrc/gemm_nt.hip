@@ -366,7 +366,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const GemmNtPara
     const unsigned int q = nblk >> 3, r = nblk & 7u;
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = L / p.ntiles_n, tile_n = L - tile_m * p.ntiles_n;
+  // Tiles in groups of group_n n-tiles, inside a group the n-tile fastest, then the m-tile: the 32 workgroups an XCD runs at a
+  // time cover (32 / group_n) m-tiles x group_n n-tiles, and the group's B rows (group_n x 256 x K: 1.5 MB at K = 768, group_n =
+  // 4) stay in the XCD's 4 MB L2 while the A rows stream past; with all n-tiles in one group (N = 2304: 3.5 MB of B) every
+  // pass over a few m-tiles re-fetched B from beyond L2.
+  int tile_m, tile_n;
+  {
+    const int gn = p.group_n;
+    const int ntm = (int)(gridDim.x / (unsigned)p.ntiles_n);
+    const int per_group = ntm * gn;
+    const int g = (int)L / per_group;
+    const int rem = (int)L - g * per_group;
+    const int width = (p.ntiles_n - g * gn < gn) ? p.ntiles_n - g * gn : gn;   // the last group may be narrower
+    tile_m = rem / width;
+    tile_n = g * gn + (rem - tile_m * width);
+  }
   const int m0 = tile_m * 256, n0 = tile_n * 256;
 
   // staging roles: instruction j of this wave is instruction q = wave*2 + j of a piece: piece rows q*8 .. +8, EIGHT lanes per
@@ -507,7 +521,11 @@ int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream) {
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
   const long long tiles = (long long)((p.M + TM - 1) / TM) * p.ntiles_n;
-  if (eight) hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3((unsigned)tiles), dim3(512), 0, stream, p);
+  if (eight) {
+    static const int gn = [] { const char* e = getenv("ICAMD_GEMM_GROUP_N"); return e ? atoi(e) : 4; }();
+    p.group_n = gn > 0 && gn < p.ntiles_n ? gn : p.ntiles_n;
+    hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3((unsigned)tiles), dim3(512), 0, stream, p);
+  }
   else if (tn == 256) hipLaunchKernelGGL(gemm_nt_kernel<256>, dim3((unsigned)tiles), dim3(512), 0, stream, p);
   else hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, stream, p);
   return icamd_launch_status();

@@ -73,6 +73,7 @@ struct GemmNtParams {
   int gelu_inplace;      // out itself receives gelu(rounded result)
   const bf16_t* gelu_z;  // optional [M][N]: out = rounded result * gelu'(gelu_z)
   int ntiles_n;          // filled by the launcher
+  int group_n;           // 8-phase kernel: n-tiles per group of its tile order (filled by the launcher)
 };
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream);
 // true when the 256x256-tile kernel is expected to beat the 128x128 implicit-GEMM kernel for this problem
