@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void pack_input_rgb4_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B,
                                                               int Cin, int H, int W, int mode, float lam, int yl, int yh,
                                                               int xl, int xh) {
-  const int Wp2 = (W + 8) / 2;
+  const int Wp2 = (W + (W & 1) + 8) / 2;        // an odd width gets one more zero column: the row pitch stays even
   const long long total = (long long)B * H * Wp2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long hw = (long long)H * W;
@@ -1050,8 +1050,8 @@ int icamd_pack_input_launch(const float* x, bf16_t* out, int B, int Cin, int H, 
 
 int icamd_pack_input_rgb4_launch(const float* x, bf16_t* out, int B, int Cin, int H, int W, int mode, float lam, int yl,
                                  int yh, int xl, int xh, hipStream_t s) {
-  if (Cin < 1 || Cin > 3 || W % 2 != 0) return ICAMD_ERR_BAD_ARG;
-  const long long total = (long long)B * H * ((W + 8) / 2);
+  if (Cin < 1 || Cin > 3) return ICAMD_ERR_BAD_ARG;
+  const long long total = (long long)B * H * ((W + (W & 1) + 8) / 2);
   hipLaunchKernelGGL(pack_input_rgb4_kernel, dim3(grid_for(total, 256, 1) * 2), dim3(256), 0, s, x, out, B, Cin, H, W, mode,
                      lam, yl, yh, xl, xh);
   return icamd_launch_status();

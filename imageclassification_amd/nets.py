@@ -408,7 +408,7 @@ class ResNet(PicklableModel):
     def _forward_eval_folded(self, ws):
         lib = self.lib
         s = hip.stream_ptr()
-        N, H, W = ws["N"], ws["H"], ws["W"]
+        N, H, W = ws["N"], ws["H"], ws["Ws"]
         if self._fold_dirty:
             self.fold_batchnorm()
         d0 = self._conv_act_eval(self.stem_conv, self.stem_bn, ws["x8"].data_ptr(), N, H, W, ws["a0"], None, True, s)
@@ -454,10 +454,12 @@ class ResNet(PicklableModel):
         def act(n, h, w, c):
             return torch.empty(n, h, w, c, dtype=torch.bfloat16, device=dev)
 
-        if W % 2:
-            raise ValueError("the ResNet stem kernels need an even input width")
-        ws["x8"] = act(N, H, W + 8, 4)      # the rgb4 stem layout (3 + 5 zero columns per row)
-        d0 = self.stem_conv.desc(N, H, W)
+        # the rgb4 stem layout (3 + 5 zero columns per row); an odd width gets one more zero column -- part of the
+        # convolution's own padding -- and the stem kernels run on the even width Ws
+        Ws = W + (W & 1)
+        ws["Ws"] = Ws
+        ws["x8"] = act(N, H, Ws + 8, 4)
+        d0 = self.stem_conv.desc(N, H, Ws)
         ws["y0"] = act(N, d0.OH, d0.OW, 64)
         ws["a0"] = act(N, d0.OH, d0.OW, 64)
         PH, PW = (d0.OH - 1) // 2 + 1, (d0.OW - 1) // 2 + 1
@@ -465,7 +467,7 @@ class ResNet(PicklableModel):
         ws["p0_idx"] = torch.empty(N, PH, PW, 64, dtype=torch.uint8, device=dev)
         max_act = max(ws["y0"].numel(), ws["x8"].numel())
         max_stats = lib.icamd_conv2d_stats_rows(ctypes.byref(d0)) * 2 * 64
-        max_wg = lib.icamd_stem7x7s2_wgrad_workspace_bytes(N, H, W, 64)
+        max_wg = lib.icamd_stem7x7s2_wgrad_workspace_bytes(N, H, Ws, 64)
         max_bnb = lib.icamd_bn_bwd_workspace_bytes(N * d0.OH * d0.OW, 64)
         h, w = PH, PW
         blocks_ws = []
@@ -595,7 +597,7 @@ class ResNet(PicklableModel):
     def forward_packed(self, ws, logits_only=False):   # logits_only: accepted for interface parity (BatchNorm needs every conv output)
         lib = self.lib
         s = hip.stream_ptr()
-        N, H, W = ws["N"], ws["H"], ws["W"]
+        N, H, W = ws["N"], ws["H"], ws["Ws"]
         if not self.training and self.fold_eval:
             return self._forward_eval_folded(ws)
         if self.training:
@@ -840,7 +842,7 @@ class ResNet(PicklableModel):
             dout, other = other, dout
 
         # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
-        d0 = self.stem_conv.desc(N, ws["H"], ws["W"])
+        d0 = self.stem_conv.desc(N, ws["H"], ws["Ws"])
         yk = next_y()
         if _FUSED_POOL_BWD:
             # max-pool backward folded into both BatchNorm-backward passes: the 112x112 gradient is never materialised
@@ -853,7 +855,7 @@ class ResNet(PicklableModel):
         else:
             hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
             bn_bwd(self.stem_bn, DA, None, ws["y0"], ypool[yk], None, True)
-        wgrad(self.stem_conv, ws["x8"].data_ptr(), ypool[yk], N, ws["H"], ws["W"], ybuf=yk)
+        wgrad(self.stem_conv, ws["x8"].data_ptr(), ypool[yk], N, ws["H"], ws["Ws"], ybuf=yk)
         for k in range(len(pending)):     # every buffer is free again when the next backward starts
             pending[k] = None
         if hook:
@@ -976,9 +978,9 @@ class ResNet(PicklableModel):
             dout, other = other, dout
 
         # stem: maxpool -> BN+ReLU -> conv (no data gradient for the image)
-        d0 = self.stem_conv.desc(N, ws["H"], ws["W"])
+        d0 = self.stem_conv.desc(N, ws["H"], ws["Ws"])
         hip.check(lib.icamd_maxpool3x3s2_bwd(dout, ws["p0_idx"].data_ptr(), DA, N, d0.OH, d0.OW, 64, s), "maxpool bwd")
         bn_bwd(self.stem_bn, DA, None, ws["y0"], Y, None, True)
-        wgrad(self.stem_conv, ws["x8"].data_ptr(), Y, N, ws["H"], ws["W"])
+        wgrad(self.stem_conv, ws["x8"].data_ptr(), Y, N, ws["H"], ws["Ws"])
         if hook:
             hook(0, None)

@@ -263,8 +263,10 @@ int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* st
 int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                      int xl, int xh, void* stream);
 
-/* ResNet stem layout: bf16 [B][H][W+8][4] -- RGB + one zero channel, 3 zero columns left and 5 right of every row, so that
- * the 7x7/2 window row of output column q is 64 contiguous 16 B-aligned bytes (W even).  Same mixing modes as above. */
+/* ResNet stem layout: bf16 [B][H][We+8][4], We = W rounded up to even -- RGB + one zero channel, 3 zero columns left and 5 (6
+ * for an odd W) right of every row, so that the 7x7/2 window row of output column q is 64 contiguous 16 B-aligned bytes.  The
+ * stem kernels are then called with IW = We: the extra zero column is part of the convolution's own zero padding, the
+ * output is that of the true width.  Same mixing modes as above. */
 int icamd_pack_input_rgb4(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                           int xl, int xh, void* stream);
 

@@ -825,7 +825,15 @@ def test_pack_input_rgb4_stem_layout(lib, mode):
     assert torch.equal(got[:, :, 3:3 + W, :3], ref)
     assert torch.equal(got[..., 3], torch.zeros(B, H, W + 8))
     assert torch.equal(got[:, :, :3], torch.zeros(B, H, 3, 4)) and torch.equal(got[:, :, 3 + W:], torch.zeros(B, H, 5, 4))
-    assert lib.icamd_pack_input_rgb4(hip.ptr(xdev), hip.ptr(out), B, 3, H, 13, 0, 1.0, 0, 0, 0, 0, hip.stream_ptr()) != 0
+    # an odd width: one more zero column on the right, the row pitch stays even ([B][H][W + 1 + 8][4])
+    xo = torch.randn(B, 3, H, 13, generator=torch.Generator().manual_seed(41))
+    outo = torch.full((B, H, 14 + 8, 4), float("nan"), dtype=torch.bfloat16, device=DEV)
+    xod = xo.to(DEV)
+    assert lib.icamd_pack_input_rgb4(hip.ptr(xod), hip.ptr(outo), B, 3, H, 13, 0, 1.0, 0, 0, 0, 0, hip.stream_ptr()) == 0
+    sync()
+    goto = outo.float().cpu()
+    assert torch.equal(goto[:, :, 3:16, :3], R.pack_input(xo, 0, 1.0, (0, 0, 0, 0))[..., :3])
+    assert torch.equal(goto[:, :, 16:], torch.zeros(B, H, 6, 4)) and torch.equal(goto[:, :, :3], torch.zeros(B, H, 3, 4))
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64), (3, 30, 34, 64), (1, 64, 64, 72), (2, 9, 8, 64),

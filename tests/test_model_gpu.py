@@ -91,6 +91,34 @@ def test_resnet18_forward_backward_within_asserted_reassociation_noise():
         assert e <= 3.0 * max(n, 5e-3), (name, e, n)
 
 
+def test_resnet18_odd_input_size_matches_oracle():
+    """Input sizes the stem layout does not fit exactly (odd width, odd height): the packed image gets one more zero column
+    and the result is that of the true size -- train-mode loss / logits and the stem filter gradient against the oracle,
+    eval-mode (BatchNorm-folded) logits too."""
+    C, B = 10, 8
+    ref, net = _timm_default_pair("resnet18", C, seed=4)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 3, 67, 61, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    ref.train()
+    out = ref(x)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    net.train()
+    ws = net.pack(x.cuda())
+    logits = net.forward_packed(ws)
+    hip_loss = _xent_backward(net, ws, y.cuda(), C)
+    assert R.rel_l2(logits[:, :C].float().cpu(), out.detach()) <= 1e-2
+    assert abs(hip_loss - float(loss)) <= 5e-3 * abs(float(loss))
+    assert R.rel_l2(net.grad_of("conv1.weight"), ref.conv1.weight.grad) <= 8e-2      # whole backward chain in bf16
+    assert R.rel_l2(net.grad_of("fc.weight"), ref.fc.weight.grad) <= 2e-2
+    ref.eval(); net.eval()
+    net.load_state_dict(ref.state_dict())          # same running statistics on both sides
+    with torch.no_grad():
+        eo = ref(x)
+    assert R.rel_l2(net(x.cuda()).float().cpu(), eo) <= 1e-2
+
+
 def _timm_default_pair(arch, num_classes, seed=0):
     """The configuration the reference really trains from: timm's ResNet init (Kaiming fan-out filters, BatchNorm weight 1 /
     bias 0, ZERO-initialised last BatchNorm weight of every residual block; /root/reference/train.py:194 create_model)."""
