@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round evidence, part A / B (one gpurun call each: a call is capped at 20 minutes).  Run on the GPU box from the repo root:
 #   ROUND=r03 bash tools/profile_round.sh A     bench lines of the three model families + rocprofv3 kernel stats
+#   ROUND=r03 bash tools/profile_round.sh C     the three bench lines again, once part B's summaries are in profiles/
 #   ROUND=r03 bash tools/profile_round.sh B     PMC passes (HBM traffic per arch, MFMA busy), per-layer / GEMM / depthwise tables
 # then, here: python tools/summarize_profiles.py gpurun_out/prof_r03 r03
 PART=${1:-A}
@@ -10,7 +11,12 @@ O=$R/gpurun_out/prof_${ROUND:-r03}
 mkdir -p $O
 VIT="--arch vit_base_patch16_224"
 CNX="--arch convnext_tiny --mixup"
-if [ "$PART" = "A" ]; then
+if [ "$PART" = "C" ]; then
+  # bench lines only (after part B's PMC summaries have been copied into profiles/: roofline.traffic is then non-null)
+  python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_r50.json 2> $O/bench_r50.err
+  python3 $R/bench.py $VIT --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_vit.json 2> $O/bench_vit.err
+  python3 $R/bench.py $CNX --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cnx.json 2> $O/bench_cnx.err
+elif [ "$PART" = "A" ]; then
   echo "== bench lines"; date
   python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_r50.json 2> $O/bench_r50.err
   python3 $R/bench.py $VIT --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_vit.json 2> $O/bench_vit.err
