@@ -499,8 +499,10 @@ int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, co
     // threads = channel pairs x strips x images: 98 304 = 1 536 waves on every ConvNeXt-T stage at batch 256; 246 VGPRs
     // allow two waves per SIMD.  The image rows are cut in two from 28 rows up (6 halo rows are re-read per part; measured
     // at batch 256: 56 x 56 x 96 forward 151 -> 137 us, 28 x 28 x 192 68 -> 61; 14 x 14 and 7 x 7 lose), and further while
-    // the grid would leave most of the chip idle.  The kernel is bound by the latency of its row loads (one row of lead:
-    // 13 dwords in flight per lane), not by its 343 v_pk_fma_f32 per row: 2.3-2.5 TB/s.
+    // the grid would leave most of the chip idle.  The kernel is VALU-bound: 343 v_pk_fma_f32 (4 cycles each on a wave64) +
+    // ~100 other instructions per input row and thread, two waves per SIMD, 1.5 rounds of the grid at stage 0 -- 55 TFLOP/s of
+    // the 157 TFLOP/s fp32 vector peak, 2.3-2.5 TB/s.  (A second row of loads in flight -- 21 taps in LDS to pay for the
+    // registers -- changed nothing: 137 -> 142 us.)
     const long long per_part = (long long)(C / 2) * nstrips * N;
     int hsplit = H >= 28 ? 2 : 1;
     while (per_part * hsplit < 1536ll * 64 / 2 && H / (hsplit * 2) >= 7) hsplit *= 2;
