@@ -103,15 +103,20 @@ def convnext_flops_per_image(net, hw):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: PMC summaries under profiles/ are stamped with it (tools/pmc_traffic.py) so that a
-    traffic figure measured on older kernels is never reported for newer ones."""
+    """sha256 over the kernel sources WITHOUT comments and whitespace: PMC summaries under profiles/ are stamped with it
+    (tools/pmc_traffic.py) so that a traffic figure measured on older kernels is never reported for newer ones, while an edit
+    of a comment does not orphan the measurement."""
     import hashlib
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "imageclassification_amd", "csrc")
+    strip = re.compile(r'//[^\n]*|/\*.*?\*/|("(?:\\.|[^"\\])*")', re.S)
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, f), encoding="utf-8", errors="replace").read()
+            text = strip.sub(lambda m: m.group(1) or " ", text)      # comments out, string literals kept
             h.update(f.encode())
-            h.update(open(os.path.join(csrc, f), "rb").read())
+            h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
