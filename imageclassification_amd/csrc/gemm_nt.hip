@@ -317,7 +317,8 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
 //     form, L2 prefetch touches (one global_load_ubyte per wave and K tile over the 512 lines of the K tile four tiles ahead):
 //     11 % slower again -- the touches sit in the same in-order vmcnt queue as the LDS-DMA the load sections wait for;
 //     LDS-DMA issued in the load section instead of among the MFMAs: the same; a ring of ten piece slots (all 160 KB of LDS,
-//     two more pieces of lead): 5-11 % slower.
+//     two more pieces of lead): 5-11 % slower; the K tiles walked from a per-tile rotated start (so that the workgroups that
+//     share a line do not all miss on it together): 3-6 % slower -- the lockstep requests merge in L2.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int PIECE = 16384, KTILE = 65536;   // bytes: one piece, one K tile (pieces in stream order A_mh0, B_nh0, B_nh1, A_mh1)
 
