@@ -71,42 +71,67 @@ static inline FastDiv make_fastdiv(unsigned int d) {
   return f;
 }
 
-// GELU (erf form, as torch.nn.GELU() / timm's Mlp use) and its derivative.  gelu(z) = z * Phi(z), 2 Phi(z) = erfc(-z / sqrt 2).
-// erfc through Abramowitz & Stegun 7.1.26 (erfc(x) = (a1 t + .. + a5 t^5) e^{-x^2}, t = 1 / (1 + p x), x >= 0; |error| <= 1.5e-7):
-// one v_rcp_f32, one v_exp_f32 and ten multiply-adds, against the ~50 instructions of the device library's erff -- which made
-// the GELU epilogues VALU-bound: ConvNeXt-T evaluates 6.6 G of them per step (fc1 forward twice under mixup, fc2 data
-// gradient), ViT-B/16 3.7 G; the 96 -> 384 forward at batch 256 ran 527 us against 220 us of HBM time.  The negative side uses
-// erfc directly (no 1 - erf cancellation); measured against fp64 over all bf16 inputs in [-9, 9]: |gelu error| <= 4.6e-7,
-// |gelu' error| <= 3.1e-7 -- three orders below the bf16 rounding of the result.
-struct GeluParts { float cdf2, e; };   // 2 Phi(z), exp(-z^2 / 2)
-__device__ __forceinline__ GeluParts gelu_parts(float z) {
-  const float x = fabsf(z) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-x * x);
-  const float q = p * t * e;                       // erfc(|z| / sqrt 2)
-  return {z < 0.f ? q : 2.f - q, e};
+// GELU (erf form, as torch.nn.GELU() / timm's Mlp use) and its derivative: gelu(z) = z Phi(z), gelu'(z) = Phi(z) + z phi(z).
+// The epilogues that apply it are VALU-bound (ConvNeXt-T evaluates 6.6 G of them per step -- fc1 forward twice under mixup,
+// fc2 data gradient --, ViT-B/16 3.7 G), so the cost per element is what counts: the device library's erff is ~50
+// instructions; Abramowitz & Stegun 7.1.26 (round 3, first form) one v_rcp_f32 + one v_exp_f32 + 14 full-rate ones.  This
+// form: the lower tail as ONE exponential of a polynomial, Phi(-u) = 2^P(u), u = min(|z|, 9.5), P = the degree-8 fit of
+// log2 Phi(-u) on [0, 9.5] (max |error| 3e-5 in fp32 Horner, i.e. 2e-5 RELATIVE in Phi(-u) down to Phi = 1e-21: the error
+// sits in the exponent, so the deep negative side needs no special case).  Two elements per
+// lane: the Horner steps are v_pk_fma_f32 (two multiply-adds per lane and issue slot), the one transcendental is v_exp_f32.
+// Against fp64 over all bf16 inputs in [-9.5, 9.5]: |gelu error| <= 1.2e-6 and <= 2.1e-5 relative, two orders below the
+// bf16 rounding of the result.  The derivative adds phi(z) = 2^(-z^2 log2(e)/2 - log2 sqrt(2 pi)): a second v_exp_f32.
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+struct GeluTail { f32x2 u, q; };   // u = min(|z|, 9.5), q = Phi(-u)
+__device__ __forceinline__ GeluTail gelu_tail2(const f32x2 z) {
+  // (v_med3_f32 with the |z| modifier: one instruction; fminf(fabsf()) adds a canonicalising v_max)
+  const f32x2 u = {__builtin_amdgcn_fmed3f(__builtin_fabsf(z[0]), 0.f, 9.5f), __builtin_amdgcn_fmed3f(__builtin_fabsf(z[1]), 0.f, 9.5f)};
+  f32x2 p = __builtin_elementwise_fma(splat2(6.770644489506594e-08f), u, splat2(-3.415887022129027e-06f));
+  p = __builtin_elementwise_fma(p, u, splat2(7.608014857396483e-05f));
+  p = __builtin_elementwise_fma(p, u, splat2(-0.000995745649561286f));
+  p = __builtin_elementwise_fma(p, u, splat2(0.00865430012345314f));
+  p = __builtin_elementwise_fma(p, u, splat2(-0.05409912392497063f));
+  p = __builtin_elementwise_fma(p, u, splat2(-0.45845112204551697f));
+  p = __builtin_elementwise_fma(p, u, splat2(-1.1512187719345093f));
+  p = __builtin_elementwise_fma(p, u, splat2(-0.9999991059303284f));
+  return {u, f32x2{__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])}};
 }
-__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * gelu_parts(z).cdf2; }
-__device__ __forceinline__ float gelu_grad_f(float z) {
-  const GeluParts g = gelu_parts(z);
-  return fmaf(z * 0.39894228040143268f, g.e, 0.5f * g.cdf2);
+// gelu(z) = z Phi(z) = max(z, 0) - u Phi(-u) on both sides of zero (z >= 0: z - z q; z < 0: z q = -u q): no select, and
+// past the clamp u q ~ 1e-20.  max(z, 0) as (z + |z|) / 2: exact, two instructions like the canonicalising fmaxf, and a NaN
+// stays a NaN.
+__device__ __forceinline__ f32x2 gelu2(const f32x2 z) {
+  const GeluTail t = gelu_tail2(z);
+  const f32x2 h = z * splat2(0.5f);
+  const f32x2 relu = {__builtin_fmaf(__builtin_fabsf(z[0]), 0.5f, h[0]), __builtin_fmaf(__builtin_fabsf(z[1]), 0.5f, h[1])};
+  return __builtin_elementwise_fma(-t.u, t.q, relu);
 }
+__device__ __forceinline__ f32x2 gelu_grad2(const f32x2 z) {
+  const GeluTail t = gelu_tail2(z);
+  const f32x2 r = splat2(1.0f) - t.q;
+  const f32x2 cdf = {z[0] < 0.f ? t.q[0] : r[0], z[1] < 0.f ? t.q[1] : r[1]};
+  const f32x2 e = __builtin_elementwise_fma(z * z, splat2(-0.72134752044448170f), splat2(-1.3257480647361593f));
+  const f32x2 phi = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+  return __builtin_elementwise_fma(z, phi, cdf);
+}
+__device__ __forceinline__ float gelu_f(float z) { return gelu2(f32x2{z, z})[0]; }
+__device__ __forceinline__ float gelu_grad_f(float z) { return gelu_grad2(f32x2{z, z})[0]; }
 // 8 bf16 values at once: a = gelu(z);  dz = da * gelu'(z)
 __device__ __forceinline__ u32x4 gelu8(const u32x4 z) {
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(gelu_f(bf16_lo(z[e])), gelu_f(bf16_hi(z[e])));
+  for (int e = 0; e < 4; ++e) {
+    const f32x2 g = gelu2(f32x2{bf16_lo(z[e]), bf16_hi(z[e])});
+    o[e] = pack_bf16x2(g[0], g[1]);
+  }
   return o;
 }
 __device__ __forceinline__ u32x4 gelu_bwd8(const u32x4 da, const u32x4 z) {
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    o[e] = pack_bf16x2(bf16_lo(da[e]) * gelu_grad_f(bf16_lo(z[e])), bf16_hi(da[e]) * gelu_grad_f(bf16_hi(z[e])));
+  for (int e = 0; e < 4; ++e) {
+    const f32x2 g = f32x2{bf16_lo(da[e]), bf16_hi(da[e])} * gelu_grad2(f32x2{bf16_lo(z[e]), bf16_hi(z[e])});
+    o[e] = pack_bf16x2(g[0], g[1]);
+  }
   return o;
 }
 

@@ -717,13 +717,20 @@ void icamd_wgrad_tile(long long M, int Ktot, int Cout, int* bmk, int* bnc) {
   // and at least ~50 GFLOP of work (ResNet's deep 3x3 and strided 1x1 layers: 100-106 us -> 78-84 us).  Smaller problems
   // are dominated by the fp32 slab traffic of the pixel split, which grows with the tile area, and by the 32-row stage's
   // barrier rate: they stay on the single-stage 128 / 64 tiles.
-  const bool big = ring_mode() != 0 && Ktot % 256 == 0 && Cout % 256 == 0 && (double)M * Ktot * Cout >= 2.5e10;
+  // (round 3) also the >= 50 GFLOP pointwise layers whose sides are multiples of 64 but not of 256 -- ConvNeXt-T's 192 <-> 768
+  // and 384 <-> 1536 Linear layers -- on the 128 x 256 / 256 x 128 ring shapes: 130-140 -> 112-124 us and 100-104 -> 87-91 us.
+  const bool work = (double)M * Ktot * Cout >= 2.5e10;
+  const bool both256 = Ktot % 256 == 0 && Cout % 256 == 0;
+  const bool wide = Ktot % 64 == 0 && Cout % 64 == 0 && (Ktot < Cout ? Ktot : Cout) >= 192 &&
+                    (pick_side(Ktot) == 256 || pick_side(Cout) == 256);
+  const bool big = ring_mode() != 0 && work && (both256 || wide);
   if (big || ring_mode() == 2) { *bmk = pick_side(Ktot); *bnc = pick_side(Cout); return; }   // mode 2: every ring shape (tests)
   *bmk = Ktot <= 64 ? 64 : 128;
   *bnc = Cout <= 64 ? 64 : 128;
 }
 
-static bool use_ring(int bmk, int bnc) { return ring_mode() == 2 || (ring_mode() == 1 && bmk == 256 && bnc == 256); }
+// mode 1: the ring kernel serves exactly the tiles with a 256 side (icamd_wgrad_tile hands those out for big problems only)
+static bool use_ring(int bmk, int bnc) { return ring_mode() == 2 || (ring_mode() == 1 && (bmk == 256 || bnc == 256)); }
 
 // workgroups of this tile shape that fit one CU (LDS- or register-limited; must match the launch table below)
 static int wgs_per_cu(int bmk, int bnc) {

@@ -318,7 +318,12 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
 //     11 % slower again -- the touches sit in the same in-order vmcnt queue as the LDS-DMA the load sections wait for;
 //     LDS-DMA issued in the load section instead of among the MFMAs: the same; a ring of ten piece slots (all 160 KB of LDS,
 //     two more pieces of lead): 5-11 % slower; the K tiles walked from a per-tile rotated start (so that the workgroups that
-//     share a line do not all miss on it together): 3-6 % slower -- the lockstep requests merge in L2.
+//     share a line do not all miss on it together): 3-6 % slower -- the lockstep requests merge in L2; the tiles of the last,
+//     partial round over the CUs (N = 768: 591 tiles = 2.31 rounds) cut 3 ways in K, the last part adding the others' fp32
+//     partial tiles in part order (sc0 sc1 stores / loads + a relaxed counter; with a release / acquire fence pair instead
+//     every part paid 40-60 us for writing back its XCD's L2): 252.6 -> 246.9 / 254.8 / 254.7 us at K = 3072, 204 -> 192-203
+//     at K = 2304, 73 -> 87 at K = 768 -- inside the run-to-run spread, because the 79 tiles of a partial round run faster
+//     than the tiles of a full one (the shared L2 -> LDS delivery is the bound, not the count of busy CUs).
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int PIECE = 16384, KTILE = 65536;   // bytes: one piece, one K tile (pieces in stream order A_mh0, B_nh0, B_nh1, A_mh1)
 

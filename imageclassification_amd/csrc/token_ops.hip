@@ -208,10 +208,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict_
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const u32x4 v = ((const u32x4*)z)[i];
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(gelu_f(bf16_lo(v[e])), gelu_f(bf16_hi(v[e])));
-    ((u32x4*)a)[i] = o;
+    ((u32x4*)a)[i] = gelu8(v);
   }
 }
 
@@ -223,11 +220,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const u32x4 g = ((const u32x4*)da)[i];
     const u32x4 v = ((const u32x4*)z)[i];
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      o[e] = pack_bf16x2(bf16_lo(g[e]) * gelu_grad_f(bf16_lo(v[e])), bf16_hi(g[e]) * gelu_grad_f(bf16_hi(v[e])));
-    ((u32x4*)dz)[i] = o;
+    ((u32x4*)dz)[i] = gelu_bwd8(g, v);
   }
 }
 

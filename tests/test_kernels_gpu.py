@@ -109,6 +109,9 @@ DGRAD_CASES = [
     (2, 8, 8, 64, 96, 2, 2, 0),       # same with Cout = 96: a single tap whose channels end mid k-step while the filter row
                                       # goes on with the other taps (found by tests/golden/convnext_ref_vectors.npz)
     (2, 10, 10, 128, 160, 2, 2, 0),
+    # even sizes, stride 2: four equal parity classes of 4 + 2 + 2 + 1 taps, several m- and n-tiles per class
+    (4, 28, 28, 128, 128, 3, 2, 1),
+    (2, 16, 16, 256, 256, 3, 2, 1),
 ]
 
 
@@ -424,6 +427,8 @@ def test_conv3x3_halo_every_tile_shape(mode):
 WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 1, 1, 0),
                             (4, 14, 14, 256, 256, 3, 1, 1),      # 256x256 ring tile: 9 filter tiles, ragged last stage
                             (3, 9, 9, 512, 256, 1, 1, 0), (2, 14, 14, 256, 512, 3, 2, 1),
+                            # ConvNeXt's Linear sides (multiples of 64, not of 256): three 128-tiles against 256-tiles in ring mode
+                            (2, 14, 14, 384, 1536, 1, 1, 0), (2, 14, 14, 1536, 384, 1, 1, 0), (3, 10, 10, 192, 768, 1, 1, 0),
                             # 3x3 / stride 1 with channel counts multiples of 64: the halo-staged kernel (image borders, chunks
                             # that straddle rows and images, ragged last chunk, several chunks per split, tiny images)
                             (2, 9, 7, 64, 128, 3, 1, 1), (3, 7, 7, 128, 64, 3, 1, 1), (5, 10, 13, 64, 64, 3, 1, 1),
@@ -1270,7 +1275,7 @@ def test_conv_dgrad_bnred(lib, case):
 
 
 @pytest.mark.parametrize("case", [(2, 10, 9, 128, 64, 1, 1, 0), (2, 12, 12, 256, 128, 1, 1, 0), (2, 9, 11, 64, 64, 3, 2, 1),
-                                  (1, 8, 8, 512, 256, 1, 1, 0)])
+                                  (1, 8, 8, 512, 256, 1, 1, 0), (2, 10, 12, 64, 128, 3, 2, 1)])
 def test_conv_dgrad_addend_on_even_grid(lib, case):
     """icamd_conv2d_dgrad_sub2 == icamd_conv2d_dgrad with the compact addend scattered into a zero tensor (bit for bit),
     and both match the oracle: the gradient a 1x1 stride-2 shortcut sends back exists on the even pixels only."""

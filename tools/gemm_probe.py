@@ -15,4 +15,8 @@ torch.cuda.synchronize(); e0.record()
 for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
-print("M %d N %d K %d: %.1f us  %.0f TFLOP/s" % (M, N, K, us, 2.0 * M * N * K / us * 1e-6))
+ref = (x[:4096].float() @ w.float().t())
+err = ((y[:4096].float() - ref).norm() / ref.norm()).item()
+ref2 = (x[-4096:].float() @ w.float().t())
+err2 = ((y[-4096:].float() - ref2).norm() / ref2.norm()).item()
+print("M %d N %d K %d: %.1f us  %.0f TFLOP/s  (rel err first / last 4096 rows %.1e %.1e)" % (M, N, K, us, 2.0 * M * N * K / us * 1e-6, err, err2))

@@ -20,7 +20,9 @@ for k, cs in sorted(acc.items()):
         m = cs["SQ_VALU_MFMA_BUSY_CYCLES"]
         print("   -> kernel cycles %.0f, MFMA busy %.1f %%" % (cyc, 100.0 * (m[0] / m[1]) / 1024.0 / cyc))
         w = cs["SQ_WAVE_CYCLES"][0] / cs["SQ_WAVE_CYCLES"][1]
-        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+            if c not in cs:
+                continue
             print("   -> %-20s %.1f %% of wave cycles" % (c, 100.0 * cs[c][0] / cs[c][1] / w))
         if "SQ_LDS_IDX_ACTIVE" in cs:
             print("   -> LDS bank-conflict share %.1f %%" % (100.0 * cs["SQ_LDS_BANK_CONFLICT"][0] / max(cs["SQ_LDS_IDX_ACTIVE"][0], 1)))
