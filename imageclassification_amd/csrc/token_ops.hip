@@ -168,6 +168,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
         sg[it][e] += d[e] * xh[it][e];
       }
     }
+    // The column sums are FINAL here, before the divergent store section below.  Left alone, hipcc sinks these packed adds past
+    // that section (to the reconvergence point), and the sums of a few lanes then depend on timing: with a second kernel on
+    // the CU (the weight-gradient stream) one row's value was missing from / doubled in ~3 % of the partial rows of the
+    // 192-channel instance -- found by the bit-reproducibility test of ConvNeXt-T at batch 256, reproduced with this kernel
+    // alone next to a ring weight gradient, gone with the sums pinned (round 3).
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      asm volatile("" : "+v"(sb[it][0]), "+v"(sb[it][1]), "+v"(sb[it][2]), "+v"(sb[it][3]), "+v"(sb[it][4]), "+v"(sb[it][5]),
+                        "+v"(sb[it][6]), "+v"(sb[it][7]));
+      asm volatile("" : "+v"(sg[it][0]), "+v"(sg[it][1]), "+v"(sg[it][2]), "+v"(sg[it][3]), "+v"(sg[it][4]), "+v"(sg[it][5]),
+                        "+v"(sg[it][6]), "+v"(sg[it][7]));
+    }
     const float c1 = group_sum<LPR>(s1) * invC, c2 = group_sum<LPR>(s2) * invC;
     if (!live) continue;
 #pragma unroll

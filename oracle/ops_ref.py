@@ -273,16 +273,19 @@ def max_bf16_ulp(a, b):
     return float(((a - b).abs() / ulp).max())
 
 
-def bf16_close(a, b, ulps=2.0, atol_rms=2e-3):
+def bf16_close(a, b, ulps=2.0, atol_rms=2e-3, max_frac=0.0):
     """Elementwise: |a-b| <= ulps * bf16 spacing at |b| + atol_rms * rms(b).
     The absolute term covers outputs that are small differences of O(rms) terms (cancellation), where a
-    different fp32 summation order legitimately moves the result by many ulps OF THE RESULT."""
+    different fp32 summation order legitimately moves the result by many ulps OF THE RESULT.
+    max_frac: share of the elements that may sit outside the bound (tests over millions of elements whose operands pass
+    through a bf16 rounding: a handful land one rounding step further out)."""
     a = a.float().flatten()
     b = b.float().flatten()
     mag = torch.maximum(a.abs(), b.abs()).clamp_min(1e-30)
     ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
     rms = float(torch.sqrt((b.double() ** 2).mean()))
-    return bool(((a - b).abs() <= ulps * ulp + atol_rms * rms).all())
+    bad = ((a - b).abs() > ulps * ulp + atol_rms * rms)
+    return bool(float(bad.float().mean()) <= max_frac)
 
 
 # ---- token ops: LayerNorm / GELU / attention (ViT, ConvNeXt) ---------------------------------------------------
