@@ -47,6 +47,8 @@ else
   bash tools/gemm_ablate.sh > $O/gemm_shapes.txt 2>&1
   python3 tools/vendor_gemm_probe.py >> $O/gemm_shapes.txt 2>&1
   python3 tools/bench_dwconv.py > $O/dwconv.txt 2>&1
+  python3 tools/bench_cnx_layers.py 256 10 2>&1 | grep -v amdgpu.ids > $O/cnx_layers.txt
+  python3 tools/bench_attn.py 256 20 2>&1 | grep -v amdgpu.ids > $O/attention.txt
   # 7 steps per PMC run: 1 warm-up + 3 timed + 3 in the per-class timing pass
   python3 tools/pmc_traffic.py $(find $O/pmc_fetch_r50 -name "*.db" | head -1) $(find $O/pmc_write_r50 -name "*.db" | head -1) 7 $O/pmc_traffic_r50.json resnet50 256
   python3 tools/pmc_traffic.py $(find $O/pmc_fetch_vit -name "*.db" | head -1) $(find $O/pmc_write_vit -name "*.db" | head -1) 7 $O/pmc_traffic_vit.json vit_base_patch16_224 256
