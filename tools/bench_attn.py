@@ -7,7 +7,7 @@ from imageclassification_amd import hip
 lib = hip.load(); s = hip.stream_ptr()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-T, H, D = 197, 12, 64
+T, H, D = 197, (int(sys.argv[3]) if len(sys.argv) > 3 else 12), 64
 scale = D ** -0.5
 g = torch.Generator(device="cuda").manual_seed(3)
 qkv = (torch.randn(B * T, 3 * H * D, device="cuda", generator=g)).bfloat16()
