@@ -1480,6 +1480,87 @@ def test_layernorm_bwd_bits_do_not_depend_on_a_second_stream(lib):
             assert torch.equal(dbet, ref[0]) and torch.equal(dgam, ref[1]) and torch.equal(dx, ref[2]), with_side
 
 
+@pytest.mark.parametrize("which", ["layernorm_bwd_c96", "layernorm_bwd_c384", "layernorm_bwd_c768", "layerscale_bwd", "colsum_rows",
+                                   "dwconv7_wgrad"])
+def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
+    """The other kernels that carry per-thread sums through a row loop with a divergent store section (the pattern behind
+    test_layernorm_bwd_bits_do_not_depend_on_a_second_stream), at the sizes the models call them with: alone and next to a ring
+    weight gradient on a second stream their outputs must be bit-identical."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    d = hip.conv_desc(256, 28, 28, 192, 768, 1, 1, 1, 0)
+    M = 256 * 28 * 28
+    xa = torch.randn(M, 192, device=DEV, generator=g).bfloat16()
+    dya = torch.randn(M, 768, device=DEV, generator=g).bfloat16()
+    wgb = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    wgw = torch.empty(wgb, dtype=torch.uint8, device=DEV)
+    dw, db = torch.empty(768, 192, device=DEV), torch.empty(768, device=DEV)
+    if which.startswith("layernorm_bwd"):
+        C = int(which.split("_c")[1])
+        rows = {96: 200704, 384: 50176, 768: 50432}[C]
+        dy = (torch.randn(rows, C, device=DEV, generator=g) * 1e-4).bfloat16()
+        x = torch.randn(rows, C, device=DEV, generator=g).bfloat16()
+        gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        y, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        assert lib.icamd_layernorm_fwd(hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), rows, C,
+                                       1e-6, main.cuda_stream) == 0
+        wsb = lib.icamd_layernorm_bwd_workspace_bytes(rows, C)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        outs = [torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)]
+
+        def run():
+            assert lib.icamd_layernorm_bwd(hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), None, hip.ptr(outs[0]),
+                                           hip.ptr(outs[1]), hip.ptr(outs[2]), rows, C, 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
+    elif which == "layerscale_bwd":
+        rows, C, rpi = 200704, 192, 784
+        dout = (torch.randn(rows, C, device=DEV, generator=g) * 1e-3).bfloat16()
+        z = torch.randn(rows, C, device=DEV, generator=g).bfloat16()
+        gamma = torch.rand(C, device=DEV, generator=g) * 1e-2
+        keep = (torch.rand(rows // rpi, device=DEV, generator=g) > 0.2).float() / 0.8
+        wsb = lib.icamd_layerscale_bwd_workspace_bytes(rows, C)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        outs = [torch.empty_like(z), torch.empty(C, device=DEV)]
+
+        def run():
+            assert lib.icamd_layerscale_bwd(hip.ptr(dout), hip.ptr(z), hip.ptr(gamma), hip.ptr(keep), hip.ptr(outs[0]), hip.ptr(outs[1]),
+                                            rows, C, rpi, 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
+    elif which == "colsum_rows":
+        rows, C = 200704, 192
+        x = (torch.randn(rows, C, device=DEV, generator=g) * 1e-3).bfloat16()
+        wsb = lib.icamd_colsum_rows_workspace_bytes(rows, C)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        outs = [torch.empty(C, device=DEV)]
+
+        def run():
+            assert lib.icamd_colsum_rows(hip.ptr(x), rows, C, C, hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
+    else:
+        N, H, W, C = 128, 28, 28, 192
+        x = torch.randn(N, H, W, C, device=DEV, generator=g).bfloat16()
+        dy = (torch.randn(N, H, W, C, device=DEV, generator=g) * 1e-3).bfloat16()
+        wsb = lib.icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        outs = [torch.empty(C, 7, 7, device=DEV)]
+
+        def run():
+            assert lib.icamd_dwconv7_wgrad(hip.ptr(x), hip.ptr(dy), hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, N, H, W, C,
+                                           main.cuda_stream) == 0
+
+    run()
+    sync()
+    ref = [o.clone() for o in outs]
+    for with_side in (False, True):
+        for _ in range(5):
+            if with_side:
+                for _ in range(3):
+                    assert lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), hip.ptr(xa), hip.ptr(dya), hip.ptr(dw), hip.ptr(db), 0,
+                                                       hip.ptr(wgw), wgb, side.cuda_stream) == 0
+            run()
+            sync()
+            for o, r in zip(outs, ref):
+                assert torch.equal(o, r), (which, with_side)
+
+
 @pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96), (3, 28, 28, 64),
                                    (2, 11, 30, 32), (70, 3, 5, 32),
                                    # rows split in two (H >= 28) with H odd, W not a multiple of 7, > 256 channel pairs per pixel
