@@ -40,6 +40,7 @@ else
   done
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_vit -- python3 $R/bench.py $VIT --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_vit.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_cnx -- python3 $R/bench.py $CNX --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_cnx.log 2>&1
   unset ICAMD_WGRAD_STREAM
   echo "== tables"; date
   cd $R
