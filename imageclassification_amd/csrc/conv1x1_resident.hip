@@ -453,6 +453,8 @@ bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend) {
   // K = 512 leaves room for 32 filter rows per wave only: measured on MI355X (batch 256) it wins on the 7x7 layers and on
   // 512 -> 256 at 28x28, ties at N = 128 and LOSES at N = 1024, M = 50176 (64 -> 83 us), so that one stays on conv_igemm
   if (K == 512 && !(M < 32768 || N == 256)) return false;
+  // K = 1024, N = 256 with one 256 x 256 tile per CU: the big-tile GEMM is faster (gemm_nt.hip, icamd_gemm_nt_wanted)
+  if (K == 1024 && N == 256 && !with_addend && icamd_gemm_nt_wanted(M, N, K)) return false;
   return M / tm * ntn >= 8 * 512;
 }
 

@@ -512,6 +512,10 @@ bool icamd_gemm_nt_wanted(long long M, int N, int K) {
   // (K >= 2048: the 7x7 layers of ResNet-50 -- 2048 -> 512 forward 52.9 -> 40.0 us, 512 -> 2048 data gradient 52.0 -> 39.1 us --
   // have only 98 tile pairs but sixty-four ring stages each)
   const long long pairs = ((M + TM - 1) / TM) * ((N + 255) / 256);
+  // (round 3, K = 1024 / N = 256 at 14x14 -- ResNet-50 layer3's 1024 -> 256 forward and 256 -> 1024 data gradient: 196 tiles,
+  // one per CU, sixteen K tiles each: 38.7 -> 30.6 us and 37.5 -> 29.5 us against the resident-filter kernel)
+  static const bool k1024 = [] { const char* e = getenv("ICAMD_GEMM_K1024"); return !(e && atoi(e) == 0); }();
+  if (k1024 && K == 1024 && N == 256 && pairs >= 160 && pairs <= 256) return true;
   return K >= 768 && N >= 256 && (pairs >= 256 || (K >= 2048 && pairs >= 96));
 }
 

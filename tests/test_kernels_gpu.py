@@ -246,7 +246,8 @@ def test_pointwise_register_resident_filter_every_shape():
 def test_pointwise_large_tile_gemm_forced_small_k(tn):
     """ICAMD_GEMM_NT=2 routes every eligible pointwise problem through gemm_nt.hip: covers 1-, 2- and 3-stage K loops and
     tiles that are mostly padding.  ICAMD_GEMM_TN=8 (the default) is the 8-phase 256 x 256 kernel wherever K % 64 == 0 --
-    K = 64 / 128 / 192 / 320 / 768: one, two, an odd number of K tiles (the 4-phase tail) and the pipelined steady state --
+    K = 64 / 128 / 192 / 320 / 768 / 1024: one, two, an odd number of K tiles (the 4-phase tail) and the pipelined steady state
+    (1024 x 256 and its transpose are ResNet-50 layer3's shape, routed here at full size: one tile per CU) --
     and the ring kernel elsewhere; 128 forces the ring kernel for all.  The switches are read once per process, hence the
     child process."""
     import subprocess
@@ -257,7 +258,8 @@ def test_pointwise_large_tile_gemm_forced_small_k(tn):
         "from imageclassification_amd import hip\n"
         "lib = hip.load()\n"
         "T._run_large_pointwise(lib, [(1, 5, 7, 32, 40), (2, 9, 9, 64, 264), (1, 20, 20, 96, 512), (3, 16, 16, 160, 72),\n"
-        "                             (1, 20, 20, 192, 512), (2, 9, 9, 320, 264), (1, 33, 31, 128, 520), (1, 40, 13, 768, 256)])\n"
+        "                             (1, 20, 20, 192, 512), (2, 9, 9, 320, 264), (1, 33, 31, 128, 520), (1, 40, 13, 768, 256),\n"
+        "                             (3, 16, 16, 1024, 256), (3, 16, 16, 256, 1024)])\n"
         "T._run_large_pointwise(lib, T.LARGE_POINTWISE)\n"
         "print('forced-ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
