@@ -477,3 +477,33 @@ def test_image_oracle_is_pillow_bit_for_bit():
     b = rng.randint(0, 256, (20, 37, 3), dtype=np.uint8)
     assert np.array_equal(I.center_square(b), np.asarray(Image.fromarray(b).crop((8, 0, 28, 20))))
     assert np.array_equal(I.center_square(b.transpose(1, 0, 2)), np.asarray(Image.fromarray(b.transpose(1, 0, 2)).crop((0, 8, 20, 28))))
+
+
+def test_gelu_constants_of_the_hip_kernels_hold_their_stated_error():
+    """csrc/common.h evaluates GELU as max(z, 0) - u * 2^P(u), u = min(|z|, 9.5), P = a degree-8 polynomial (the constants are
+    read from the header, so the test follows them).  The same arithmetic in numpy float32 over EVERY bf16 value in
+    [-9.5, 9.5] against the erf definition in fp64: the error bounds the header states (1.2e-6 absolute, 2.1e-5 relative) --
+    two orders below the bf16 rounding of the result -- and the derivative form Phi(z) + z phi(z)."""
+    from scipy.special import ndtr
+    src = open(os.path.join(ROOT, "imageclassification_amd", "csrc", "common.h")).read()
+    body = src[src.index("gelu_tail2(const f32x2 z)"):src.index("return {u, f32x2{")]
+    coef = [float(m) for m in re.findall(r"splat2\((-?[0-9.e+-]+)f\)", body)]
+    assert len(coef) == 9, coef                                   # highest degree first
+    bits = np.arange(0, 1 << 16, dtype=np.uint32)
+    z = (bits << 16).view(np.float32)
+    z = z[np.isfinite(z) & (np.abs(z) <= 9.5)]
+    u = np.minimum(np.abs(z), np.float32(9.5)).astype(np.float32)
+    p = np.full_like(u, np.float32(coef[0]))
+    for c in coef[1:]:
+        p = (p * u + np.float32(c)).astype(np.float32)            # (the kernel fuses the multiply-add: one rounding fewer)
+    q = np.exp2(p.astype(np.float64))                             # Phi(-u)
+    gelu = np.maximum(z, 0).astype(np.float64) - u.astype(np.float64) * q
+    ref = z.astype(np.float64) * ndtr(z.astype(np.float64))
+    err = np.abs(gelu - ref)
+    assert err.max() <= 1.5e-6, err.max()
+    nz = np.abs(ref) > 0
+    assert (err[nz] / np.abs(ref[nz])).max() <= 3e-5
+    cdf = np.where(z < 0, q, 1.0 - q)
+    phi = np.exp2(z.astype(np.float64) ** 2 * -0.72134752044448170 - 1.3257480647361593)
+    grad_ref = ndtr(z.astype(np.float64)) + z.astype(np.float64) * np.exp(-0.5 * z.astype(np.float64) ** 2) / math.sqrt(2 * math.pi)
+    assert np.abs(cdf + z * phi - grad_ref).max() <= 3e-6
