@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // dx = rstd * (dy*gamma - mean_C(dy*gamma) - xhat * mean_C(dy*gamma*xhat)) (+ addend); per-workgroup partial column
 // sums of dy (-> dbeta) and dy*xhat (-> dgamma) in part[blk][2][C].  Each wave walks `rows_per_wave` rows, 64/LPR at a time.
 template <int LPR>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const bf16_t* __restrict__ addend,
                                                             bf16_t* __restrict__ dx, float* __restrict__ part, long long rows,
@@ -110,12 +110,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   const int sub = lane % LPR, grp = lane / LPR;
   const int nvec = C >> 3;
   const bool has[2] = {sub < nvec, sub + LPR < nvec};
-  float g[2][8], sb[2][8], sg[2][8];
+  // Column sums (d beta, d gamma) and gamma as PACKED pairs in the order the 16 B vectors hold them (element 2e in .x, 2e + 1
+  // in .y): every pair the packed-fp32 instructions see is then a natural VGPR pair and no op_sel swizzle is needed.  That is
+  // a correctness matter on this part, not a style one -- see the note at the accumulation below.
+  f32x2 g2[2][4], sb[2][4], sg[2][4];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int c = (has[it] ? sub + it * LPR : 0) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { g[it][e] = gamma[c + e]; sb[it][e] = 0.f; sg[it][e] = 0.f; }
+    for (int e = 0; e < 4; ++e) {
+      g2[it][e] = f32x2{gamma[c + 2 * e], gamma[c + 2 * e + 1]};
+      sb[it][e] = f32x2{0.f, 0.f};
+      sg[it][e] = f32x2{0.f, 0.f};
+    }
   }
   const float invC = 1.f / (float)C;
   const long long r0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
@@ -151,51 +158,44 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
     for (int it = 0; it < 2; ++it) { rd[it] = nd[it]; rx[it] = nx[it]; ra[it] = na[it]; }
     if (rbase + RPW < r1) fetch(rbase + RPW);
-    float dyg[2][8], xh[2][8];
+    f32x2 dyg[2][4], xh[2][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      float d[8], xv[8];
-      unpack8(rd[it], d);
-      unpack8(rx[it], xv);
+      const bool on = has[it] && live;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        xh[it][e] = (has[it] && live) ? (xv[e] - mu) * rs : 0.f;
-        dyg[it][e] = d[e] * g[it][e];
-        s1 += dyg[it][e];
-        s2 += dyg[it][e] * xh[it][e];
-        sb[it][e] += d[e];
-        sg[it][e] += d[e] * xh[it][e];
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 d = {bf16_lo(rd[it][e]), bf16_hi(rd[it][e])};
+        const f32x2 xv = {bf16_lo(rx[it][e]), bf16_hi(rx[it][e])};
+        const f32x2 xn = (xv - mu) * rs;
+        xh[it][e] = f32x2{on ? xn.x : 0.f, on ? xn.y : 0.f};
+        dyg[it][e] = d * g2[it][e];
+        const f32x2 p = dyg[it][e] * xh[it][e];
+        s1 += dyg[it][e].x + dyg[it][e].y;
+        s2 += p.x + p.y;
+        // HARDWARE NOTE (round 4, tools/hazard_probe/, DESIGN 5 "round-4 finding 1"): written element by element
+        // (sb[8] += d[e]), hipcc's SLP vectoriser paired the sums across vector boundaries and emitted
+        // `v_pk_add_f32 vD, vD, vS op_sel:[0,1] op_sel_hi:[1,0]`.  On this MI355X a packed-fp32 instruction whose LOW result
+        // takes the HIGH register of a source pair returns a wrong low result in lanes 48-63 while another wave of the SIMD
+        // executes MFMAs with VGPR accumulators (the weight-gradient stream): a few rows of the 192-channel instance lost one
+        // row's value.  Natural pairs need no op_sel; tools/isa_lint.py fails the build if one ever appears again.
+        sb[it][e] += d;
+        sg[it][e] += d * xh[it][e];
       }
-    }
-    // The column sums are FINAL here, before the divergent store section below.  Left alone, hipcc sinks these packed adds past
-    // that section (to the reconvergence point), and the sums of a few lanes then depend on timing: with a second kernel on
-    // the CU (the weight-gradient stream) one row's value was missing from / doubled in ~3 % of the partial rows of the
-    // 192-channel instance -- found by the bit-reproducibility test of ConvNeXt-T at batch 256, reproduced with this kernel
-    // alone next to a ring weight gradient, gone with the sums pinned (round 3).
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      asm volatile("" : "+v"(sb[it][0]), "+v"(sb[it][1]), "+v"(sb[it][2]), "+v"(sb[it][3]), "+v"(sb[it][4]), "+v"(sb[it][5]),
-                        "+v"(sb[it][6]), "+v"(sb[it][7]));
-      asm volatile("" : "+v"(sg[it][0]), "+v"(sg[it][1]), "+v"(sg[it][2]), "+v"(sg[it][3]), "+v"(sg[it][4]), "+v"(sg[it][5]),
-                        "+v"(sg[it][6]), "+v"(sg[it][7]));
     }
     const float c1 = group_sum<LPR>(s1) * invC, c2 = group_sum<LPR>(s2) * invC;
     if (!live) continue;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
       if (has[it]) {
-        float o[8];
+        u32x4 ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (dyg[it][e] - c1 - xh[it][e] * c2);
-        if (addend != nullptr) {   // residual branch: the skip connection's gradient joins here
-          float a8[8];
-          unpack8(ra[it], a8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += a8[e];
+        for (int e = 0; e < 4; ++e) {
+          f32x2 o = (dyg[it][e] - c1 - xh[it][e] * c2) * rs;
+          if (addend != nullptr) o += f32x2{bf16_lo(ra[it][e]), bf16_hi(ra[it][e])};   // the skip connection's gradient joins here
+          ov[e] = pack_bf16x2(o.x, o.y);
         }
-        *(u32x4*)(dx + ro + (sub + it * LPR) * 8) = pack8(o);
+        *(u32x4*)(dx + ro + (sub + it * LPR) * 8) = ov;
       }
   }
   // fold: lane groups of the wave (fixed xor order), then the 4 waves in wave order; one partial row per workgroup
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   for (int it = 0; it < 2; ++it)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float b = cross_group_sum<LPR>(sb[it][e]), gg = cross_group_sum<LPR>(sg[it][e]);
+      const float b = cross_group_sum<LPR>(sb[it][e >> 1][e & 1]), gg = cross_group_sum<LPR>(sg[it][e >> 1][e & 1]);
       if (grp == 0 && has[it]) {
         red[wave][0][(sub + it * LPR) * 8 + e] = b;
         red[wave][1][(sub + it * LPR) * 8 + e] = gg;
