@@ -3,9 +3,15 @@
 
 A "step" is one pass of the hot path (engine.train_one_epoch body: input pack, forward, label-smoothed loss,
 backward, gradient all-reduce, fused AdamW, device-side metrics) over one synthetic batch already resident in
-HBM.  Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel class, timed live with HIP events
-on the launch stream over the timed region; `cpu_baseline` is the CPU oracle of the same step (torch-CPU fp32
-restatement of the reference loop) timed on this box's host cores on a bounded sample.
+HBM.  Prints ONE JSON line on rank 0.  `roofline` is for the kernel class that takes the most time of ALL classes,
+timed live with HIP events on the launch stream; `roofline_classes` carries every class (time, calls, algorithmic
+bytes and flops booked by the C ABI per call, both roof fractions), `roofline_step` the blended whole step,
+`host_enqueue_ms` the Python / launch time one step needs with no device wait; `cpu_baseline` is the CPU oracle of
+the same step (torch-CPU fp32 restatement of the reference loop) timed on this box's host cores on a bounded sample.
+
+`--mode eval` measures the other half of the named hot path the same way: engine.evaluate (reference
+engine.py:145-225) over device-resident batches of int(1.5 * 256) = 384 images (the reference's eval batch,
+train.py:167), BatchNorm folded into the filters.
 """
 import argparse
 import contextlib
@@ -102,6 +108,32 @@ def convnext_flops_per_image(net, hw):
     return layers
 
 
+# every kernel a C-ABI call of the class can launch, by name prefix (csrc/capi.hip routing), for the PMC traffic figures.
+# Kernels shared between classes (conv_igemm serves forward and data gradient; the fp32 slab fold serves every weight
+# gradient) are listed under every class they serve and the traffic is then reported for the GROUP of classes that share.
+_FD = ("conv_igemm_kernel", "conv1x1_resident_kernel", "conv3x3_halo_kernel", "conv3x3_c64_resident_kernel",
+       "stem7x7s2_resident_kernel", "gemm_nt_kernel", "gemm_nt_8phase_kernel")
+CLASS_KERNELS = {
+    "conv_fwd": _FD, "conv_dgrad": _FD,
+    "conv_wgrad": ("conv_wgrad_kernel", "conv_wgrad_ring_kernel", "conv3x3_wgrad_halo_kernel", "stem7x7s2_wgrad_resident_kernel",
+                   "slab_reduce_kernel"),
+    "bn_finalize": ("bn_reduce_finalize_kernel", "bn_eval_coeffs", "bn_fold"),
+    "bn_apply": ("bn_apply_kernel", "bn_relu_maxpool"),
+    "bn_bwd": ("bn_bwd_",),
+    "pool": ("maxpool3x3s2_", "avgpool_"),
+    "pack": ("pack_input",),
+    "loss": ("softmax_xent_kernel", "step_metrics_kernel"),
+    "optimizer": ("adamw_ema_kernel", "optim_ema_kernel", "filter_transpose", "sumsq_partial_kernel", "gradnorm_finalize_kernel",
+                  "lerp_kernel", "f32_to_bf16_kernel", "grad_guard"),
+    "misc": ("colsum_kernel", "colsum_partial_kernel", "vit_tokens_fwd_kernel", "batch_sum_kernel", "strided_rows_copy_kernel"),
+    "attn_fwd": ("attn_fwd_kernel",), "attn_bwd": ("attn_bwd_",),
+    "ln_fwd": ("layernorm_fwd_kernel",), "ln_bwd": ("layernorm_bwd_kernel",),
+    "elementwise": ("layerscale_", "gelu_fwd_kernel", "gelu_bwd_kernel"),
+    "dwconv": ("dwconv7_",),
+}
+MFMA_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "attn_fwd", "attn_bwd")
+
+
 def kernel_source_hash():
     """sha256 over the kernel sources WITHOUT comments and whitespace: PMC summaries under profiles/ are stamped with it
     (tools/pmc_traffic.py) so that a traffic figure measured on older kernels is never reported for newer ones, while an edit
@@ -171,9 +203,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU and step (default 256; 384 with --mode eval)")
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--hw", type=int, default=224)
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="train: engine.train_one_epoch (the headline); eval: engine.evaluate on batches of 384")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mixup", action="store_true", help="mixup 0.8 + cutmix 1.0 + EMA (BASELINE configs[4] recipe)")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -184,6 +218,9 @@ def main():
                     help="gradient transport at N > 1: torch.distributed's RCCL process group (default) or the library's own "
                          "RCCL communicator (icamd_allreduce_bucket_launch)")
     args = ap.parse_args()
+    is_eval = args.mode == "eval"
+    if args.batch is None:
+        args.batch = 384 if is_eval else 256     # reference train.py:167: the eval loader uses int(1.5 * batch_size)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
@@ -213,7 +250,8 @@ def main():
 
     from imageclassification_amd import hip
     from imageclassification_amd.ddp import DistributedDataParallel
-    from imageclassification_amd.engine import train_one_epoch
+    from imageclassification_amd import engine
+    from imageclassification_amd.engine import evaluate, train_one_epoch
     from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
     from imageclassification_amd.nets import ResNet
     from imageclassification_amd.vit import CONFIGS as VIT_CONFIGS, VisionTransformer
@@ -242,7 +280,7 @@ def main():
     opt = create_optimizer("adamw", 1e-3, 5e-4, net)
     crit = LabelSmoothingCrossEntropy(0.1)
     mixup_fn, model_ema = None, None
-    if args.mixup:   # BASELINE configs[4]: mixup 0.8 + cutmix 1.0 (soft targets) + model EMA 0.9995
+    if args.mixup and not is_eval:   # BASELINE configs[4]: mixup 0.8 + cutmix 1.0 (soft targets) + model EMA 0.9995
         import numpy as np
         np.random.seed(88 + rank)
         mixup_fn = Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=C)
@@ -261,6 +299,8 @@ def main():
     def run(nsteps, start):
         loader = [pool[i % len(pool)] for i in range(nsteps)]
         with contextlib.redirect_stdout(sink):
+            if is_eval:
+                return evaluate(loader, model, device, C, use_amp=True)
             return train_one_epoch(model, crit, loader, opt, device, 0, NativeScalerWithGradNormCount(), None, model_ema, mixup_fn,
                                    start_steps=start, lr_schedule_values=lr, wd_schedule_values=wd,
                                    num_training_steps_per_epoch=nsteps, update_freq=1, use_amp=True, num_classes=C)
@@ -279,16 +319,20 @@ def main():
     stats = run(args.steps, args.warmup)
     barrier()
     dt = time.perf_counter() - t0
+    # host side of the same K steps: the loop enqueues them back to back and waits once at its end (engine.py), so the
+    # time it took to get there is what Python + the HIP launches cost; the device waits on the host only if this exceeds dt
+    enqueue_s = (evaluate if is_eval else train_one_epoch).last_enqueue_s
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     value = world * B * args.steps / dt
-    log(f"timed {args.steps} steps: {1e3 * dt / args.steps:.2f} ms/step, {value:.1f} img/s")
+    log(f"timed {args.steps} steps: {1e3 * dt / args.steps:.2f} ms/step, {value:.1f} img/s; host enqueue "
+        f"{1e3 * enqueue_s / args.steps:.2f} ms/step")
 
     # Second pass over the same workload with HIP events recorded around every C-ABI call on the launch stream
-    # (icamd_prof_*): per-kernel-class durations for the roofline object.  Kept out of the headline timing because the
-    # ~1500 event records per step cost ~10 % of the step.
+    # (icamd_prof_*): per-kernel-class durations and the algorithmic bytes / flops the C ABI books per call.  Kept out of
+    # the headline timing because the ~1500 event records per step cost ~10 % of the step.
     prof_steps = min(args.steps, 10)
     # The timed region above runs the weight gradients on a second stream beside the main chain; co-running kernels
     # stretch one another, so for per-kernel rates this pass keeps everything on ONE stream (the rocprofv3 summaries of
@@ -303,133 +347,137 @@ def main():
     dt_prof = time.perf_counter() - t1
     lib.icamd_prof_enable(0)
     net.wgrad_side_stream = True
-    prof = hip.prof_collect()
+    prof = hip.prof_collect(work=True)
     psteps = prof_steps
 
     if rank == 0:
-        layers = vit_flops_per_image(net) if is_vit else (convnext_flops_per_image(net, HW)[:-1] if is_cnx
-                                                           else conv_flops_per_image(net, HW))
-        fwd_flops = sum(f for _, f in layers) * B           # per step, all conv/FC (and attention) forward launches
-        stem_flops = layers[0][1] * B
-        # the mixup recipe runs the reference's second (train-accuracy) forward: two forward passes per step
-        nfwd = 2 if (args.mixup and os.environ.get("ICAMD_CHEAP_MIXUP_ACC", "0") != "1") else 1
-        algo = {"conv_fwd": fwd_flops * nfwd, "conv_dgrad": fwd_flops - stem_flops, "conv_wgrad": fwd_flops}
-        kern = {}
-        for k, (ms, calls) in prof.items():
-            if calls:
-                kern[k] = {"ms_per_step": ms / psteps, "calls_per_step": calls / psteps}
-        mfma_classes = [k for k in ("conv_fwd", "conv_dgrad", "conv_wgrad") if k in kern]
-        dom = max(mfma_classes, key=lambda k: kern[k]["ms_per_step"])
-        ach = algo[dom] / (kern[dom]["ms_per_step"] * 1e-3) / 1e12
-        per_launch_flops = algo[dom] / kern[dom]["calls_per_step"]
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/): only used when
-        # the summary was collected for THIS workload on THESE kernel sources (hash stamp), else null + a note
-        traffic, traffic_note = None, None
-        pmc_file = args.pmc_file or {"resnet50": "r03_pmc_traffic.json", "vit_base_patch16_224": "r03_pmc_traffic_vit.json",
-                                     "convnext_tiny": "r03_pmc_traffic_convnext.json"}.get(args.arch, "r03_pmc_traffic.json")
-        pmc_path = os.path.join(ROOT, "profiles", pmc_file)
-        # every kernel a C-ABI call of the class can launch (csrc/capi.hip routing), by name prefix.  The weight-gradient kernels
-        # serve that class only (its fp32 slab fold included); the forward and data-gradient calls share their kernels, so for
-        # those two classes the PMC bytes are averaged over the launches of BOTH (said in traffic_note).
-        wgrad_names = ("conv_wgrad_kernel", "conv_wgrad_ring_kernel", "conv3x3_wgrad_halo_kernel", "stem7x7s2_wgrad_resident_kernel",
-                       "slab_reduce_kernel")
-        fd_names = ("conv_igemm_kernel", "conv1x1_resident_kernel", "conv3x3_halo_kernel", "conv3x3_c64_resident_kernel",
-                    "stem7x7s2_resident_kernel", "gemm_nt_kernel", "gemm_nt_8phase_kernel", "attn_fwd_kernel", "attn_bwd")
+        ms_step = 1e3 * dt / args.steps
+        # ---- every class: time, calls, algorithmic work (booked per call by the C ABI), both roof fractions
+        classes = {}
+        for k, (ms, calls, nbytes, flops) in prof.items():
+            if not calls:
+                continue
+            sec = ms * 1e-3 / psteps
+            c = {"ms_per_step": round(ms / psteps, 3), "calls_per_step": calls / psteps,
+                 "algorithmic_GB_per_step": round(nbytes / psteps / 1e9, 3),
+                 "GBps": round(nbytes / psteps / sec / 1e9, 1) if sec > 0 else None,
+                 "hbm_frac": round(nbytes / psteps / sec / 1e9 / PEAK_HBM_GBS, 4) if sec > 0 else None}
+            if flops:
+                c["algorithmic_TFLOP_per_step"] = round(flops / psteps / 1e12, 4)
+                c["tflops"] = round(flops / psteps / sec / 1e12, 1)
+                c["mfma_frac"] = round(flops / psteps / sec / 1e12 / PEAK_BF16_TFLOPS, 4)
+            c["bound"] = "mfma" if (k in MFMA_CLASSES and c.get("mfma_frac", 0) > (c["hbm_frac"] or 0)) else "hbm"
+            classes[k] = c
+        dom = max(classes, key=lambda k: classes[k]["ms_per_step"])
+
+        # ---- HBM bytes from the committed rocprofv3 --pmc passes (profiles/): only used when the summary was collected for THIS
+        # workload on THESE kernel sources (hash stamp), else null + a note
+        pmc, traffic_note = None, None
+        default_pmc = {"resnet50": "r04_pmc_traffic.json", "vit_base_patch16_224": "r04_pmc_traffic_vit.json",
+                       "convnext_tiny": "r04_pmc_traffic_convnext.json"}.get(args.arch, "r04_pmc_traffic.json")
+        if is_eval:
+            default_pmc = "r04_pmc_traffic_eval.json"
+        pmc_file = args.pmc_file or default_pmc
         try:
-            pmc = json.load(open(pmc_path))
-            if pmc.get("workload", {}).get("arch") != args.arch or pmc.get("workload", {}).get("batch") != B:
+            doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            wl = doc.get("workload", {})
+            if wl.get("arch") != args.arch or wl.get("batch") != B or wl.get("mode", "train") != args.mode:
                 traffic_note = f"{pmc_file} was collected for another workload"
-            elif pmc.get("kernel_source_hash") != kernel_source_hash():
-                traffic_note = (f"stale: {pmc_file} was collected on kernel sources {pmc.get('kernel_source_hash')}, "
+            elif doc.get("kernel_source_hash") != kernel_source_hash():
+                traffic_note = (f"stale: {pmc_file} was collected on kernel sources {doc.get('kernel_source_hash')}, "
                                 f"this build is {kernel_source_hash()}")
             else:
-                names = wgrad_names if dom == "conv_wgrad" else fd_names
-                sel = [v for k, v in pmc["kernels"].items() if k.startswith(names)]
-                per_step = sum(v["fetch_GB_per_step"] + v["write_GB_per_step"] for v in sel) * 1e9
-                calls = kern[dom]["calls_per_step"]
-                if dom != "conv_wgrad":
-                    calls = sum(kern[k]["calls_per_step"] for k in ("conv_fwd", "conv_dgrad") if k in kern)
-                    traffic_note = ("forward and data-gradient calls share their kernels: PMC bytes of those kernels averaged over "
-                                    "the launches of both classes")
-                traffic = round(per_step / calls)
-        except (OSError, KeyError, ValueError, ZeroDivisionError) as e:
+                pmc = doc
+        except (OSError, KeyError, ValueError) as e:
             traffic_note = f"no usable PMC summary ({type(e).__name__})"
-        avg_us = round(1e3 * kern[dom]["ms_per_step"] / kern[dom]["calls_per_step"], 2)
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_us": avg_us, "algorithmic_gflop_per_launch": round(per_launch_flops / 1e9, 3)}
+
+        def pmc_bytes(names):
+            return sum(v["fetch_GB_per_step"] + v["write_GB_per_step"] for k, v in pmc["kernels"].items() if k.startswith(names)) * 1e9
+
+        # the classes whose kernels the dominant class shares (forward + data gradient): PMC bytes are per kernel NAME, so the
+        # per-launch traffic is the average over the launches of the whole group -- said in traffic_scope, not hidden
+        group = [k for k in classes if CLASS_KERNELS.get(k) == CLASS_KERNELS.get(dom)]
+        traffic = None
+        if pmc is not None:
+            per_step = pmc_bytes(CLASS_KERNELS[dom])
+            calls = sum(classes[k]["calls_per_step"] for k in group)
+            traffic = round(per_step / calls) if calls else None
+            for k, c in classes.items():
+                if [g_ for g_ in classes if CLASS_KERNELS.get(g_) == CLASS_KERNELS.get(k)] == [k]:
+                    c["pmc_GB_per_step"] = round(pmc_bytes(CLASS_KERNELS[k]) / 1e9, 3)
+        d = classes[dom]
+        by_flops = d["bound"] == "mfma"
+        per_launch = (prof[dom][3] if by_flops else prof[dom][2]) / prof[dom][1]
+        roofline = {"kernel": dom, "bound": d["bound"],
+                    "achieved": d["tflops"] if by_flops else d["GBps"], "peak": PEAK_BF16_TFLOPS if by_flops else PEAK_HBM_GBS,
+                    "unit": "TFLOP/s" if by_flops else "GB/s", "frac": d["mfma_frac"] if by_flops else d["hbm_frac"],
+                    "traffic": traffic, "traffic_scope": "+".join(group),
+                    "avg_launch_us": round(1e3 * d["ms_per_step"] / d["calls_per_step"], 2),
+                    ("algorithmic_gflop_per_launch" if by_flops else "algorithmic_mbytes_per_launch"):
+                        round(per_launch / (1e9 if by_flops else 1e6), 3),
+                    "hbm_frac": d["hbm_frac"], "mfma_frac": d.get("mfma_frac")}
         if traffic_note:
             roofline["traffic_note"] = traffic_note
-        lb = getattr(conv_flops_per_image, "layer_bytes", None)
-        roofline_classes = {}
-        if lb is not None:
-            # every MFMA class against both roofs (the `roofline` object below is the one of the class that takes the most time)
-            for cls in mfma_classes:
-                lbc = lb[1:] if cls == "conv_dgrad" else lb
-                passes_c = nfwd if cls == "conv_fwd" else 1
-                act_c = sum(i + o for i, o, _ in lbc) * B * passes_c
-                if cls == "conv_dgrad" and not (is_vit or is_cnx):
-                    act_c += getattr(conv_flops_per_image, "dgrad_extra", 0) * B
-                wts_c = sum(w_ for _, _, w_ in lbc) * (4 if cls == "conv_wgrad" else 2) * passes_c
-                sec = kern[cls]["ms_per_step"] * 1e-3
-                roofline_classes[cls] = {"ms_per_step": round(kern[cls]["ms_per_step"], 3),
-                                         "calls_per_step": kern[cls]["calls_per_step"],
-                                         "tflops": round(algo[cls] / sec / 1e12, 1),
-                                         "mfma_frac": round(algo[cls] / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                         "algorithmic_GB_per_step": round((act_c + wts_c) / 1e9, 3),
-                                         "hbm_frac": round((act_c + wts_c) / sec / 1e9 / PEAK_HBM_GBS, 4)}
-        if lb is not None:
-            # The same launches against the HBM roof: algorithmic bytes = each layer's input + output activations once
-            # (bf16) + its filters (bf16 shadow read by fwd/dgrad; fp32 gradient written by wgrad).  ResNet's convolutions
-            # have 64-512 channels, so most launches move more time's worth of bytes than of flops: report whichever roof
-            # the class sits closer to, and keep the other fraction beside it.
-            if dom == "conv_dgrad":
-                lb = lb[1:]
-            passes = nfwd if dom == "conv_fwd" else 1
-            act = sum(i + o for i, o, _ in lb) * B * passes
-            if dom == "conv_dgrad" and not (is_vit or is_cnx):
-                act += getattr(conv_flops_per_image, "dgrad_extra", 0) * B
-            wts = sum(w for _, _, w in lb) * (4 if dom == "conv_wgrad" else 2) * passes
-            gbs = (act + wts) / (kern[dom]["ms_per_step"] * 1e-3) / 1e9
-            roofline["mfma_frac"] = roofline["frac"]
-            roofline["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
-            roofline["algorithmic_mbytes_per_launch"] = round((act + wts) / kern[dom]["calls_per_step"] / 1e6, 3)
-            if gbs / PEAK_HBM_GBS > roofline["frac"]:
-                roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": roofline["hbm_frac"]})
-        for k in mfma_classes:
-            kern[k]["tflops"] = round(algo[k] / (kern[k]["ms_per_step"] * 1e-3) / 1e12, 2)
-        for k in kern:
-            kern[k]["ms_per_step"] = round(kern[k]["ms_per_step"], 3)
+
+        # ---- the whole step against both roofs (SURVEY 8d "blended"): algorithmic work of all classes over the TIMED step
+        tot_bytes = sum(v[2] for v in prof.values()) / psteps
+        tot_flops = sum(v[3] for v in prof.values()) / psteps
+        step = {"ms_per_step": round(ms_step, 3), "algorithmic_GB": round(tot_bytes / 1e9, 2),
+                "GBps": round(tot_bytes / (ms_step * 1e-3) / 1e9, 1), "hbm_frac": round(tot_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "algorithmic_TFLOP": round(tot_flops / 1e12, 3), "tflops": round(tot_flops / (ms_step * 1e-3) / 1e12, 1),
+                "mfma_frac": round(tot_flops / (ms_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "pmc_GB": None, "kernel_ms_single_stream": round(sum(c["ms_per_step"] for c in classes.values()), 3),
+                "note": "algorithmic_GB = every operand of every C-ABI call once (as the step is built: unfused passes count); "
+                        "pmc_GB = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of all kernels of a step (profiles/)"}
+        if pmc is not None:
+            step["pmc_GB"] = round(pmc["total_fetch_GB_per_step"] + pmc["total_write_GB_per_step"], 2)
+            step["pmc_over_algorithmic"] = round(step["pmc_GB"] / step["algorithmic_GB"], 3)
+        if not (is_vit or is_cnx or is_eval):
+            # SURVEY 8(d)'s ideal-fusion figure for ResNet: 24 B per conv-output element + 36 B per parameter
+            layers = conv_flops_per_image(net, HW)
+            elems = sum(o for _, o, _ in conv_flops_per_image.layer_bytes[:-1]) / 2
+            step["survey_ideal_GB"] = round((24 * elems * B + 36 * net.n_params) / 1e9, 2)
+
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            from oracle.engine_ref import time_cpu_training
+        if not args.no_cpu_baseline and world == 1 and not (is_vit or is_cnx):
+            from oracle.engine_ref import time_cpu_eval, time_cpu_training
             ncpu = host_cores()
             log(f"cpu baseline on {ncpu} threads ...")
             with contextlib.redirect_stdout(sink):
-                ips, threads, sps = time_cpu_training(args.arch, 32, HW, C, warmup=args.cpu_warmup, steps=args.cpu_steps,
-                                                      threads=ncpu)
+                ips, threads, sps = (time_cpu_eval if is_eval else time_cpu_training)(
+                    args.arch, 32, HW, C, warmup=args.cpu_warmup, steps=args.cpu_steps, threads=ncpu)
+            what = ("engine.py evaluate" if is_eval else "engine.py train_one_epoch")
             cpu = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
                    "cpu_model": cpu_model_string(),
                    "sample": f"{args.cpu_steps} timed steps of batch 32 after {args.cpu_warmup} warm-up steps, torch-CPU fp32 "
-                             f"restatement of engine.py train_one_epoch, {args.arch} {HW}x{HW}, AdamW+label smoothing"}
+                             f"restatement of {what}, {args.arch} {HW}x{HW}" + ("" if is_eval else ", AdamW+label smoothing")}
         label = {"resnet50": "ResNet-50", "vit_base_patch16_224": "ViT-B/16", "convnext_tiny": "ConvNeXt-T"}.get(args.arch, args.arch)
-        if args.mixup:
+        if args.mixup and not is_eval:
             label += " + mixup/cutmix + EMA"
-        out = {"metric": f"images/sec (whole node) {label} bf16 {HW}^2 training", "value": round(value, 2),
+        cfg_i = 3 if is_vit else (4 if is_cnx else (1 if world == 1 else 2))
+        if is_eval:
+            workload = (f"{args.arch} evaluate (engine.py:145-225), synthetic 3x{HW}x{HW}, batch {B}/GPU = int(1.5 x 256) "
+                        f"(train.py:167), 1000 classes, BatchNorm folded (the eval half of BASELINE north_star's hot path)")
+        else:
+            workload = (f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, label smoothing 0.1, 1000 classes "
+                        f"(BASELINE configs[{cfg_i}])")
+        out = {"metric": f"images/sec (whole node) {label} bf16 {HW}^2 " + ("evaluation" if is_eval else "training"),
+               "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{args.arch} train step, synthetic 3x{HW}x{HW}, batch {B}/GPU, AdamW, "
-                                      f"label smoothing 0.1, 1000 classes (BASELINE configs[{3 if is_vit else (4 if is_cnx else (1 if world == 1 else 2))}])",
-                          "global_batch": B * world, "parallelism": f"dp{world}"},
-               "n_ranks_seen": ranks_seen, "roofline": roofline, "roofline_classes": roofline_classes, "cpu_baseline": cpu,
-               "kernels": kern,
+               "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}"},
+               "n_ranks_seen": ranks_seen, "roofline": roofline, "roofline_classes": classes, "roofline_step": step,
+               "host_enqueue_ms": round(1e3 * enqueue_s / args.steps, 3),
+               "host_enqueue_frac": round(enqueue_s / (dt if dt > 0 else 1), 3),
+               "cpu_baseline": cpu,
+               "kernels": {k: {"ms_per_step": c["ms_per_step"], "calls_per_step": c["calls_per_step"]} for k, c in classes.items()},
                "kernel_source_hash": kernel_source_hash(),
                "kernel_timing": {"method": "HIP events on the launch stream around every C-ABI call; separate single-stream pass "
                                            "(the timed region overlaps weight gradients on a second stream)",
                                  "steps": psteps, "ms_per_step_with_events": round(1e3 * dt_prof / psteps, 3)},
-               "train_stats": {k: round(v, 5) for k, v in stats.items()}}
+               ("eval_stats" if is_eval else "train_stats"): {k: round(v, 5) for k, v in stats.items()
+                                                              if not k.startswith(("precision_", "recall_"))}}
         print(json.dumps(out))
     if world > 1:
         model.shutdown()            # destroys the library's own communicator when one was made

@@ -100,8 +100,11 @@ int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base
 #include <vector>
 namespace {
 enum ProfClass { PC_IGEMM_FWD = 0, PC_IGEMM_DGRAD, PC_WGRAD, PC_BN_FINALIZE, PC_BN_APPLY, PC_BN_BWD, PC_POOL, PC_PACK,
-                 PC_LOSS, PC_OPTIM, PC_MISC, PC_COUNT };
-struct ProfRec { int cls; hipEvent_t a, b; };
+                 PC_LOSS, PC_OPTIM, PC_MISC, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_ELEMWISE, PC_DWCONV, PC_COUNT };
+// Besides the elapsed time every call books its ALGORITHMIC work (round 4): bytes = each operand tensor of the call
+// read once and each result written once at the stored width (bf16 activations, fp32 parameters / gradients), two-pass
+// kernels counted as the two passes they are; flops = 2 x multiply-adds of the contraction.  bench.py divides by the time.
+struct ProfRec { int cls; hipEvent_t a, b; double bytes, flops; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
@@ -110,14 +113,26 @@ hipEvent_t prof_event() {
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 struct ProfScope {
-  int cls; hipStream_t s; hipEvent_t a; bool on;
+  int cls; hipStream_t s; hipEvent_t a; bool on; double bytes = 0.0, flops = 0.0;
   ProfScope(int c, void* stream) : cls(c), s((hipStream_t)stream), on(g_prof_on) {
     if (on) { a = prof_event(); (void)hipEventRecord(a, s); }
   }
+  void work(double b, double f = 0.0) { bytes = b; flops = f; }
   ~ProfScope() {
-    if (on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, s); g_prof_recs.push_back({cls, a, b}); }
+    if (on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, s); g_prof_recs.push_back({cls, a, b, bytes, flops}); }
   }
 };
+// operand sizes of a convolution call: input / output activations (bf16), filter elements, multiply-adds x 2
+struct ConvWork { double in, out, w, flops; };
+static ConvWork conv_work(const icamd_conv_desc* d) {
+  ConvWork c = {0, 0, 0, 0};
+  if (d == nullptr) return c;
+  c.in = 2.0 * d->N * d->IH * d->IW * d->Cin;
+  c.out = 2.0 * d->N * d->OH * d->OW * d->Cout;
+  c.w = (double)d->Cout * d->KH * d->KW * d->Cin;
+  c.flops = 2.0 * d->N * d->OH * d->OW * c.w;
+  return c;
+}
 }  // namespace
 
 namespace {
@@ -139,12 +154,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
 
-int icamd_abi_version(void) { return 3; }
+int icamd_abi_version(void) { return 4; }
 
 int icamd_prof_enable(int on) { g_prof_on = on != 0; return ICAMD_OK; }
 int icamd_prof_classes(void) { return PC_COUNT; }
 // Synchronises the recorded events, adds per-class elapsed ms / call counts into the arrays, clears the log.
-int icamd_prof_collect(double* ms, long long* calls, int n) {
+int icamd_prof_collect(double* ms, long long* calls, double* bytes, double* flops, int n) {
   if (ms == nullptr || calls == nullptr || n < PC_COUNT) return ICAMD_ERR_BAD_ARG;
   for (auto& r : g_prof_recs) {
     (void)hipEventSynchronize(r.b);
@@ -152,6 +167,8 @@ int icamd_prof_collect(double* ms, long long* calls, int n) {
     (void)hipEventElapsedTime(&t, r.a, r.b);
     ms[r.cls] += (double)t;
     calls[r.cls] += 1;
+    if (bytes != nullptr) bytes[r.cls] += r.bytes;
+    if (flops != nullptr) flops[r.cls] += r.flops;
     g_prof_pool.push_back(r.a);
     g_prof_pool.push_back(r.b);
   }
@@ -226,18 +243,21 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
 int icamd_conv2d_fwd(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                      const void* addend, float* stats, void* stream) {
   ProfScope _prof(PC_IGEMM_FWD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.in + cw.out + 2 * cw.w + (addend ? cw.out : 0), cw.flops);
   return conv_fwd_impl(d, x, w, y, bias, addend, stats, 0, stream);
 }
 
 int icamd_conv2d_fwd_act(const icamd_conv_desc* d, const void* x, const void* w, void* y, const float* bias,
                          const void* addend, int relu, void* stream) {
   ProfScope _prof(PC_IGEMM_FWD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.in + cw.out + 2 * cw.w + (addend ? cw.out : 0), cw.flops);
   return conv_fwd_impl(d, x, w, y, bias, addend, nullptr, relu ? 1 : 0, stream);
 }
 
 int icamd_conv2d_fwd_gelu(const icamd_conv_desc* d, const void* x, const void* w, void* z, void* a, const float* bias,
                           void* stream) {
   ProfScope _prof(PC_IGEMM_FWD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.in + (z ? cw.out : 0) + cw.out + 2 * cw.w, cw.flops);
   if (a == nullptr) return ICAMD_ERR_BAD_ARG;
   if (z == nullptr) return conv_fwd_impl(d, x, w, a, bias, nullptr, nullptr, 0, stream, nullptr, /*gelu_inplace=*/1);
   return conv_fwd_impl(d, x, w, z, bias, nullptr, nullptr, 0, stream, a);
@@ -247,6 +267,7 @@ int icamd_bn_fold_filters(const float* w, const float* gamma, const float* beta,
                           const float* running_var, float eps, int Cout, int K, void* w_folded, float* shift,
                           void* stream) {
   ProfScope _prof(PC_BN_FINALIZE, stream);
+  _prof.work(6.0 * Cout * K);
   if (w == nullptr || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr ||
       w_folded == nullptr || shift == nullptr || Cout <= 0 || K <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -350,6 +371,7 @@ static int dgrad_impl(const icamd_conv_desc* d, const void* dy, const void* w_t,
 int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend,
                        const uint8_t* addend_maskbits, void* stream) {
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.out + cw.in + 2 * cw.w + (addend ? cw.in : 0) + (addend_maskbits ? cw.in / 16 : 0), cw.flops);
   if (addend_maskbits != nullptr && (addend == nullptr || d == nullptr || d->Cin % 64 != 0)) return ICAMD_ERR_BAD_ARG;
   return dgrad_impl(d, dy, w_t, dx, addend, addend_maskbits, nullptr, stream);
 }
@@ -357,6 +379,7 @@ int icamd_conv2d_dgrad(const icamd_conv_desc* d, const void* dy, const void* w_t
 int icamd_conv2d_dgrad_sub2(const icamd_conv_desc* d, const void* dy, const void* w_t, void* dx, const void* addend_sub2,
                             void* stream) {
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.out + cw.in + 2 * cw.w + cw.in / 4, cw.flops);
   if (addend_sub2 == nullptr) return ICAMD_ERR_BAD_ARG;
   return dgrad_impl(d, dy, w_t, dx, addend_sub2, nullptr, nullptr, stream, nullptr, 1);
 }
@@ -364,6 +387,7 @@ int icamd_conv2d_dgrad_sub2(const icamd_conv_desc* d, const void* dy, const void
 int icamd_conv2d_dgrad_gelu(const icamd_conv_desc* d, const void* dy, const void* w_t, const void* z, void* dz,
                             void* stream) {
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.out + 2 * cw.in + 2 * cw.w, cw.flops);
   if (z == nullptr) return ICAMD_ERR_BAD_ARG;
   return dgrad_impl(d, dy, w_t, dz, nullptr, nullptr, nullptr, stream, z);
 }
@@ -382,6 +406,7 @@ int icamd_conv2d_dgrad_stats_rows(const icamd_conv_desc* d) {
 int icamd_conv2d_dgrad_bnbwd(const icamd_conv_desc* d, const void* dy, const void* w_t, void* g, const void* addend,
                              const icamd_bn_bwd_fuse* f, void* stream) {
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.out + 2 * cw.in + 2 * cw.w + (addend ? cw.in : 0), cw.flops);
   if (f == nullptr || f->y == nullptr || f->mean == nullptr || f->invstd == nullptr || f->partials == nullptr)
     return ICAMD_ERR_BAD_ARG;
   return dgrad_impl(d, dy, w_t, g, addend, nullptr, f, stream);
@@ -396,6 +421,7 @@ int icamd_conv2d_dgrad_bnred(const icamd_conv_desc* d, const void* dy, const voi
                              const uint8_t* addend_bits, int addend_sub2, const void* bn_y, const uint8_t* bn_bits,
                              float* partials, void* stream) {
   ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.out + 3 * cw.in + 2 * cw.w + cw.in / 16 + (addend_bits ? cw.in / 16 : 0), cw.flops);
   if (!conv_desc_ok(d) || dy == nullptr || w_t == nullptr || g == nullptr || addend == nullptr || bn_y == nullptr ||
       bn_bits == nullptr || partials == nullptr || (addend_sub2 && addend_bits != nullptr))
     return ICAMD_ERR_BAD_ARG;
@@ -431,12 +457,14 @@ static int wgrad_impl(const icamd_conv_desc* d, const void* x, const void* dy, f
 int icamd_conv2d_wgrad(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_WGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.in + cw.out + 4 * cw.w, cw.flops);
   return wgrad_impl(d, x, dy, dw, nullptr, accumulate, workspace, workspace_bytes, stream);
 }
 
 int icamd_conv2d_wgrad_bias(const icamd_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                             int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_WGRAD, stream);
+  const ConvWork cw = conv_work(d); _prof.work(cw.in + cw.out + 4 * cw.w, cw.flops);
   if (dbias == nullptr) return ICAMD_ERR_BAD_ARG;
   return wgrad_impl(d, x, dy, dw, dbias, accumulate, workspace, workspace_bytes, stream);
 }
@@ -470,6 +498,7 @@ static int wgrad_impl(const icamd_conv_desc* d, const void* x, const void* dy, f
 int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
                            void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work(4.0 * 4096 * njobs);
   if (src_base == nullptr || dst_base == nullptr || descs == nullptr || jobs == nullptr || njobs < 0) return ICAMD_ERR_BAD_ARG;
   return icamd_filter_transpose_launch((const bf16_t*)src_base, (bf16_t*)dst_base, (const long long*)descs, jobs, njobs,
                                        (hipStream_t)stream);
@@ -478,6 +507,7 @@ int icamd_filter_transpose(const void* src_base, void* dst_base, const int64_t* 
 int icamd_filter_transpose_tiled(const void* src_base, void* dst_base, const int64_t* descs, const int32_t* jobs, int njobs,
                                  void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work(4.0 * 4096 * njobs);
   if (src_base == nullptr || dst_base == nullptr || descs == nullptr || jobs == nullptr || njobs < 0) return ICAMD_ERR_BAD_ARG;
   return icamd_filter_transpose_tiled_launch((const bf16_t*)src_base, (bf16_t*)dst_base, (const long long*)descs, jobs, njobs,
                                              (hipStream_t)stream);
@@ -492,6 +522,7 @@ int icamd_bn_train_finalize(const float* partials, int nrows, int C, double coun
                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                             float* mean, float* invstd, float* scale, float* shift, void* workspace, void* stream) {
   ProfScope _prof(PC_BN_FINALIZE, stream);
+  _prof.work(8.0 * nrows * C);
   if (partials == nullptr || nrows <= 0 || C <= 0 || count <= 0 || gamma == nullptr || beta == nullptr ||
       mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr || workspace == nullptr || C > 4096)
     return ICAMD_ERR_BAD_ARG;
@@ -502,6 +533,7 @@ int icamd_bn_train_finalize(const float* partials, int nrows, int C, double coun
 int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, void* stream) {
   ProfScope _prof(PC_BN_FINALIZE, stream);
+  _prof.work(24.0 * C);
   if (C <= 0 || gamma == nullptr || beta == nullptr || running_mean == nullptr || running_var == nullptr ||
       scale == nullptr || shift == nullptr)
     return ICAMD_ERR_BAD_ARG;
@@ -511,6 +543,7 @@ int icamd_bn_eval_coeffs(int C, const float* gamma, const float* beta, const flo
 int icamd_bn_apply(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                    uint8_t* maskbits, long long numel, int C, int relu, void* stream) {
   ProfScope _prof(PC_BN_APPLY, stream);
+  _prof.work((double)numel * (4 + (residual ? 2 : 0)) + (maskbits ? numel / 8.0 : 0));
   if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || numel <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_bn_apply_launch((const bf16_t*)y, scale, shift, (const bf16_t*)residual, (bf16_t*)out, maskbits, numel, C,
                                relu, (hipStream_t)stream);
@@ -520,6 +553,7 @@ int icamd_bn_apply_res_bn(const void* y, const float* scale, const float* shift,
                           const float* res_shift, void* out, uint8_t* maskbits, long long numel, int C, int relu,
                           void* stream) {
   ProfScope _prof(PC_BN_APPLY, stream);
+  _prof.work((double)numel * 6 + (maskbits ? numel / 8.0 : 0));
   if (y == nullptr || scale == nullptr || shift == nullptr || res_y == nullptr || res_scale == nullptr ||
       res_shift == nullptr || out == nullptr || numel <= 0 || C <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -540,6 +574,7 @@ int icamd_bn_bwd(const void* dout, const void* act, const void* y, const float* 
                  const uint8_t* maskbits, long long rows, int C, int relu, int accumulate, void* workspace,
                  size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
+  _prof.work((double)rows * C * (2 * (4 + (act ? 2 : 0)) + 2 + (gout ? 2 : 0)) + (maskbits ? rows * C / 4.0 : 0));
   if (dout == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr || shift == nullptr ||
       dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 || C <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -564,6 +599,7 @@ int icamd_bn_bwd_maxpool3x3s2(const void* dout_pooled, const uint8_t* idx, const
                               void* dy, int N, int IH, int IW, int C, int accumulate, void* workspace, size_t workspace_bytes,
                               void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
+  _prof.work((double)N * IH * IW * C * (2 * 2 + 2) + 2.0 * N * IH * IW * C / 4 * 3);
   if (dout_pooled == nullptr || idx == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr ||
       shift == nullptr || dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || N <= 0 || IH <= 0 ||
       IW <= 0 || C <= 0 || C % 8 != 0)
@@ -590,6 +626,7 @@ int icamd_bn_bwd_dual(const void* dout, const uint8_t* maskbits, const void* yA,
                       const float* invstdB, const float* scaleB, float* dgammaB, float* dbetaB, void* dyB, long long rows, int C,
                       int accumulate, void* workspaceA, void* workspaceB, size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
+  _prof.work((double)rows * C * (2 * 6 + 4) + rows * C / 4.0);
   if (dout == nullptr || maskbits == nullptr || yA == nullptr || yB == nullptr || meanA == nullptr || meanB == nullptr ||
       invstdA == nullptr || invstdB == nullptr || scaleA == nullptr || scaleB == nullptr || dgammaA == nullptr ||
       dgammaB == nullptr || dbetaA == nullptr || dbetaB == nullptr || dyA == nullptr || dyB == nullptr ||
@@ -624,6 +661,7 @@ int icamd_bn_bwd_from_partials(const float* partials, int nrows, const void* g, 
                                long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
+  _prof.work((double)rows * C * 6 + 8.0 * nrows * C);
   if (partials == nullptr || nrows <= 0 || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr ||
       scale == nullptr || dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 ||
       C <= 0 || C % 8 != 0)
@@ -642,6 +680,7 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
                                   long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream) {
   ProfScope _prof(PC_BN_BWD, stream);
+  _prof.work((double)rows * C * 6 + 8.0 * nrows * C);
   if (partials == nullptr || nrows <= 0 || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr ||
       scale == nullptr || dgamma == nullptr || dbeta == nullptr || dy == nullptr || workspace == nullptr || rows <= 0 ||
       C <= 0 || C % 8 != 0)
@@ -658,7 +697,8 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
 // ---- LayerNorm / GELU / column sums (ViT, ConvNeXt) -------------------------------------------------------------
 int icamd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                         long long rows, int C, float eps, void* stream) {
-  ProfScope _prof(PC_BN_APPLY, stream);
+  ProfScope _prof(PC_LN_FWD, stream);
+  _prof.work((double)rows * C * 4 + 8.0 * rows);
   if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || mean == nullptr || rstd == nullptr || rows <= 0 ||
       C <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -675,7 +715,8 @@ size_t icamd_layernorm_bwd_workspace_bytes(long long rows, int C) {
 int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         const void* addend, void* dx, float* dgamma, float* dbeta, long long rows, int C, int accumulate,
                         void* workspace, size_t workspace_bytes, void* stream) {
-  ProfScope _prof(PC_BN_BWD, stream);
+  ProfScope _prof(PC_LN_BWD, stream);
+  _prof.work((double)rows * C * (6 + (addend ? 2 : 0)) + 8.0 * rows);
   if (dy == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || gamma == nullptr || dx == nullptr ||
       dgamma == nullptr || dbeta == nullptr || workspace == nullptr || rows <= 0 || C <= 0 || C > 4096)
     return ICAMD_ERR_BAD_ARG;
@@ -693,13 +734,15 @@ int icamd_layernorm_bwd(const void* dy, const void* x, const float* mean, const 
 }
 
 int icamd_gelu_fwd(const void* z, void* a, long long numel, void* stream) {
-  ProfScope _prof(PC_BN_APPLY, stream);
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(4.0 * numel);
   if (z == nullptr || a == nullptr || numel <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_gelu_fwd_launch((const bf16_t*)z, (bf16_t*)a, numel, (hipStream_t)stream);
 }
 
 int icamd_gelu_bwd(const void* da, const void* z, void* dz, long long numel, void* stream) {
-  ProfScope _prof(PC_BN_BWD, stream);
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(6.0 * numel);
   if (da == nullptr || z == nullptr || dz == nullptr || numel <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_gelu_bwd_launch((const bf16_t*)da, (const bf16_t*)z, (bf16_t*)dz, numel, (hipStream_t)stream);
 }
@@ -714,6 +757,7 @@ size_t icamd_colsum_rows_workspace_bytes(long long rows, int cols) {
 int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* out, int accumulate, void* workspace,
                       size_t workspace_bytes, void* stream) {
   ProfScope _prof(PC_MISC, stream);
+  _prof.work(2.0 * rows * cols);
   if (x == nullptr || out == nullptr || workspace == nullptr || rows <= 0 || cols <= 0 || cols > 4096 || ld < cols)
     return ICAMD_ERR_BAD_ARG;
   if (workspace_bytes < icamd_colsum_rows_workspace_bytes(rows, cols)) return ICAMD_ERR_WORKSPACE;
@@ -732,6 +776,7 @@ int icamd_colsum_rows(const void* x, long long rows, int ld, int cols, float* ou
 int icamd_vit_tokens_fwd(const void* patches, const float* cls_token, const float* pos_embed, void* tokens, int B, int T, int C,
                          void* stream) {
   ProfScope _prof(PC_MISC, stream);
+  _prof.work(4.0 * B * T * C);
   if (patches == nullptr || cls_token == nullptr || pos_embed == nullptr || tokens == nullptr || B <= 0 || T <= 1 || C <= 0)
     return ICAMD_ERR_BAD_ARG;
   return icamd_vit_tokens_fwd_launch((const bf16_t*)patches, cls_token, pos_embed, (bf16_t*)tokens, B, T, C, (hipStream_t)stream);
@@ -739,6 +784,7 @@ int icamd_vit_tokens_fwd(const void* patches, const float* cls_token, const floa
 
 int icamd_batch_sum(const void* x, long long stride, int B, long long n, float* out, int accumulate, void* stream) {
   ProfScope _prof(PC_MISC, stream);
+  _prof.work(2.0 * B * n);
   if (x == nullptr || out == nullptr || B <= 0 || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_batch_sum_launch((const bf16_t*)x, stride, B, n, out, accumulate, (hipStream_t)stream);
 }
@@ -746,6 +792,7 @@ int icamd_batch_sum(const void* x, long long stride, int B, long long n, float* 
 int icamd_strided_rows_copy(const void* src, long long src_stride, void* dst, long long dst_stride, long long rows, long long C,
                             void* stream) {
   ProfScope _prof(PC_MISC, stream);
+  _prof.work(4.0 * rows * C);
   if (src == nullptr || dst == nullptr || rows <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_strided_rows_copy_launch((const bf16_t*)src, src_stride, (bf16_t*)dst, dst_stride, rows, C, (hipStream_t)stream);
 }
@@ -757,13 +804,15 @@ int icamd_fill_zero(void* ptr, size_t bytes, void* stream) {
 
 // ---- ConvNeXt: depthwise 7x7 + layer scale / stochastic depth / residual ------------------------------------------
 int icamd_dwconv7_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int C, void* stream) {
-  ProfScope _prof(PC_POOL, stream);
+  ProfScope _prof(PC_DWCONV, stream);
+  _prof.work(4.0 * N * H * W * C, 98.0 * N * H * W * C);
   if (x == nullptr || w == nullptr || y == nullptr || N <= 0 || H <= 0 || W <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_dwconv7_launch((const bf16_t*)x, (const bf16_t*)w, bias, nullptr, (bf16_t*)y, N, H, W, C, 0, (hipStream_t)stream);
 }
 
 int icamd_dwconv7_dgrad(const void* dy, const void* w, const void* addend, void* dx, int N, int H, int W, int C, void* stream) {
-  ProfScope _prof(PC_POOL, stream);
+  ProfScope _prof(PC_DWCONV, stream);
+  _prof.work((4.0 + (addend ? 2 : 0)) * N * H * W * C, 98.0 * N * H * W * C);
   if (dy == nullptr || w == nullptr || dx == nullptr || N <= 0 || H <= 0 || W <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_dwconv7_launch((const bf16_t*)dy, (const bf16_t*)w, nullptr, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, 1,
                               (hipStream_t)stream);
@@ -776,7 +825,8 @@ size_t icamd_dwconv7_wgrad_workspace_bytes(int N, int H, int W, int C) {
 
 int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
                         int N, int H, int W, int C, void* stream) {
-  ProfScope _prof(PC_POOL, stream);
+  ProfScope _prof(PC_DWCONV, stream);
+  _prof.work(4.0 * N * H * W * C, 98.0 * N * H * W * C);
   if (x == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
   const size_t need = icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C);
   if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
@@ -786,7 +836,8 @@ int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate
 
 int icamd_layerscale_fwd(const void* z, const void* inp, const float* gamma, const float* keep, void* out, long long rows, int C,
                          long long rows_per_image, void* stream) {
-  ProfScope _prof(PC_BN_APPLY, stream);
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(6.0 * rows * C);
   if (z == nullptr || inp == nullptr || gamma == nullptr || out == nullptr || rows <= 0 || C <= 0 || rows_per_image <= 0)
     return ICAMD_ERR_BAD_ARG;
   return icamd_layerscale_fwd_launch((const bf16_t*)z, (const bf16_t*)inp, gamma, keep, (bf16_t*)out, rows, C, rows_per_image,
@@ -802,7 +853,8 @@ size_t icamd_layerscale_bwd_workspace_bytes(long long rows, int C) {
 int icamd_layerscale_bwd(const void* dout, const void* z, const float* gamma, const float* keep, void* dz, float* dgamma,
                          long long rows, int C, long long rows_per_image, int accumulate, void* workspace,
                          size_t workspace_bytes, void* stream) {
-  ProfScope _prof(PC_BN_BWD, stream);
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(6.0 * rows * C);
   if (dout == nullptr || z == nullptr || gamma == nullptr || dz == nullptr || dgamma == nullptr || workspace == nullptr ||
       rows <= 0 || C <= 0 || C > 4096 || rows_per_image <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -822,7 +874,8 @@ int icamd_layerscale_bwd(const void* dout, const void* z, const float* gamma, co
 
 // ---- attention (ViT) --------------------------------------------------------------------------------------------
 int icamd_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, float scale, void* stream) {
-  ProfScope _prof(PC_IGEMM_FWD, stream);
+  ProfScope _prof(PC_ATTN_FWD, stream);
+  _prof.work(8.0 * B * T * H * D, 4.0 * B * H * (double)T * T * D);
   if (qkv == nullptr || out == nullptr || lse == nullptr || B <= 0 || T <= 0 || H <= 0) return ICAMD_ERR_BAD_ARG;
   if (D != 64) return ICAMD_ERR_UNSUPPORTED;
   return icamd_attention_fwd_launch((const bf16_t*)qkv, (bf16_t*)out, lse, B, T, H, scale, (hipStream_t)stream);
@@ -830,7 +883,8 @@ int icamd_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, in
 
 int icamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                         int B, int T, int H, int D, float scale, void* stream) {
-  ProfScope _prof(PC_IGEMM_DGRAD, stream);
+  ProfScope _prof(PC_ATTN_BWD, stream);
+  _prof.work(16.0 * B * T * H * D, 10.0 * B * H * (double)T * T * D);
   if (qkv == nullptr || out == nullptr || dout == nullptr || lse == nullptr || delta == nullptr || dqkv == nullptr || B <= 0 ||
       T <= 0 || H <= 0)
     return ICAMD_ERR_BAD_ARG;
@@ -841,6 +895,7 @@ int icamd_attention_bwd(const void* qkv, const void* out, const void* dout, cons
 
 int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int IH, int IW, int C, void* stream) {
   ProfScope _prof(PC_POOL, stream);
+  _prof.work((double)N * IH * IW * C * (2 + 0.75));
   if (x == nullptr || out == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
   return icamd_maxpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, argmax, N, IH, IW, C, OH, OW, (hipStream_t)stream);
@@ -849,6 +904,7 @@ int icamd_maxpool3x3s2_fwd(const void* x, void* out, uint8_t* argmax, int N, int
 int icamd_bn_relu_maxpool3x3s2_fwd(const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, int N,
                                    int IH, int IW, int C, void* stream) {
   ProfScope _prof(PC_BN_APPLY, stream);
+  _prof.work((double)N * IH * IW * C * (2 + 0.75));
   if (y == nullptr || scale == nullptr || shift == nullptr || out == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0)
     return ICAMD_ERR_BAD_ARG;
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
@@ -858,6 +914,7 @@ int icamd_bn_relu_maxpool3x3s2_fwd(const void* y, const float* scale, const floa
 
 int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int IH, int IW, int C, void* stream) {
   ProfScope _prof(PC_POOL, stream);
+  _prof.work((double)N * IH * IW * C * (2 + 0.75));
   if (dout == nullptr || argmax == nullptr || dx == nullptr || N <= 0 || IH <= 0 || IW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   const int OH = (IH + 2 - 3) / 2 + 1, OW = (IW + 2 - 3) / 2 + 1;
   return icamd_maxpool_bwd_launch((const bf16_t*)dout, argmax, (bf16_t*)dx, N, IH, IW, C, OH, OW, (hipStream_t)stream);
@@ -865,12 +922,14 @@ int icamd_maxpool3x3s2_bwd(const void* dout, const uint8_t* argmax, void* dx, in
 
 int icamd_avgpool_fwd(const void* x, void* out, int N, int HW, int C, void* stream) {
   ProfScope _prof(PC_POOL, stream);
+  _prof.work(2.0 * N * HW * C + 2.0 * N * C);
   if (x == nullptr || out == nullptr || N <= 0 || HW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_avgpool_fwd_launch((const bf16_t*)x, (bf16_t*)out, N, HW, C, (hipStream_t)stream);
 }
 
 int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* stream) {
   ProfScope _prof(PC_POOL, stream);
+  _prof.work(2.0 * N * HW * C + 2.0 * N * C);
   if (dout == nullptr || dx == nullptr || N <= 0 || HW <= 0 || C <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_avgpool_bwd_launch((const bf16_t*)dout, (bf16_t*)dx, N, HW, C, (hipStream_t)stream);
 }
@@ -878,6 +937,7 @@ int icamd_avgpool_bwd(const void* dout, void* dx, int N, int HW, int C, void* st
 int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                      int xl, int xh, void* stream) {
   ProfScope _prof(PC_PACK, stream);
+  _prof.work((mode ? 8.0 : 4.0) * B * Cin * H * W + 16.0 * B * H * W);
   if (x == nullptr || out == nullptr || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return ICAMD_ERR_BAD_ARG;
   if (mode != 0 && (B % 2) != 0) return ICAMD_ERR_BAD_ARG;  // timm Mixup asserts an even batch
   return icamd_pack_input_launch(x, (bf16_t*)out, B, Cin, H, W, mode, lam, yl, yh, xl, xh, (hipStream_t)stream);
@@ -886,6 +946,7 @@ int icamd_pack_input(const float* x, void* out, int B, int Cin, int H, int W, in
 int icamd_pack_input_rgb4(const float* x, void* out, int B, int Cin, int H, int W, int mode, float lam, int yl, int yh,
                           int xl, int xh, void* stream) {
   ProfScope _prof(PC_PACK, stream);
+  _prof.work((mode ? 8.0 : 4.0) * B * Cin * H * W + 8.0 * B * H * (W + 8));
   if (x == nullptr || out == nullptr || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return ICAMD_ERR_BAD_ARG;
   return icamd_pack_input_rgb4_launch(x, (bf16_t*)out, B, Cin, H, W, mode, lam, yl, yh, xl, xh, (hipStream_t)stream);
 }
@@ -903,6 +964,10 @@ int icamd_stem7x7s2_stats_rows(int N, int H, int W) {
 int icamd_stem7x7s2_fwd(const void* x4, const void* w, void* y, const float* bias, float* stats, int relu, int N, int H,
                         int W, int Cout, void* stream) {
   ProfScope _prof(PC_IGEMM_FWD, stream);
+  {   // rgb4 layout in, [N][OH][OW][Cout] out, [Cout][8][8][4] filters; 147 real taps per output
+    const double oh = (H - 1) / 2 + 1, ow = (W - 1) / 2 + 1;
+    _prof.work(8.0 * N * H * (W + 8) + 2.0 * N * oh * ow * Cout + 512.0 * Cout, 2.0 * N * oh * ow * Cout * 147);
+  }
   if (x4 == nullptr || w == nullptr || y == nullptr || !stem_shape_ok(N, H, W, Cout)) return ICAMD_ERR_BAD_ARG;
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;   // (H + 6 - 7) / 2 + 1
   if ((long long)N * OH * OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
@@ -940,6 +1005,10 @@ size_t icamd_stem7x7s2_wgrad_workspace_bytes(int N, int H, int W, int Cout) {
 int icamd_stem7x7s2_wgrad(const void* x4, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
                           int N, int H, int W, int Cout, void* stream) {
   ProfScope _prof(PC_WGRAD, stream);
+  {
+    const double oh = (H - 1) / 2 + 1, ow = (W - 1) / 2 + 1;
+    _prof.work(8.0 * N * H * (W + 8) + 2.0 * N * oh * ow * Cout + 1024.0 * Cout, 2.0 * N * oh * ow * Cout * 147);
+  }
   if (x4 == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
   const size_t need = icamd_stem7x7s2_wgrad_workspace_bytes(N, H, W, Cout);
   if (need == 0) return ICAMD_ERR_BAD_ARG;
@@ -969,6 +1038,7 @@ int icamd_stem7x7s2_wgrad(const void* x4, const void* dy, float* dw, int accumul
 int icamd_softmax_xent(const void* logits, int ld, int B, int C, const int64_t* y1, const int64_t* y2, float lam,
                        float smoothing, float gscale, float* loss_rows, int32_t* pred, void* dlogits, void* stream) {
   ProfScope _prof(PC_LOSS, stream);
+  _prof.work(4.0 * B * ld);
   if (logits == nullptr || y1 == nullptr || loss_rows == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_softmax_xent_launch((const bf16_t*)logits, ld, B, C, (const long long*)y1, (const long long*)y2, lam,
                                    smoothing, gscale, loss_rows, pred, (bf16_t*)dlogits, (hipStream_t)stream);
@@ -978,6 +1048,7 @@ int icamd_step_metrics(const float* loss_rows, const int32_t* pred, const int64_
                        float* loss_out, int32_t* finite_out, double* acc_f64, int32_t* counts, float* loss_log,
                        int log_slot, int log_stride, int respect_skip, void* stream) {
   ProfScope _prof(PC_LOSS, stream);
+  _prof.work(16.0 * B);
   if (loss_out == nullptr || finite_out == nullptr || acc_f64 == nullptr || B <= 0) return ICAMD_ERR_BAD_ARG;
   if (pred != nullptr && target == nullptr) return ICAMD_ERR_BAD_ARG;
   if (loss_rows == nullptr && pred == nullptr && !(respect_skip & 4)) return ICAMD_ERR_BAD_ARG;
@@ -990,6 +1061,7 @@ size_t icamd_grad_norm_workspace_bytes(void) { return 512 * sizeof(double); }
 int icamd_grad_norm(const float* g, long long n, float inv_scale, float max_norm, void* workspace, float* out,
                     void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work(4.0 * n);
   if (g == nullptr || n <= 0 || workspace == nullptr || out == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_grad_norm_launch(g, n, inv_scale, max_norm, (double*)workspace, out, (hipStream_t)stream);
 }
@@ -998,6 +1070,7 @@ int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sh
                     float beta1, float beta2, float eps, int step, float gscale, float ema_decay, const float* clip,
                     const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work((30.0 + (ema ? 8 : 0)) * n);
   if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_adamw_ema_launch(p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale, ema_decay,
                                 clip, finite_flag, skipped_steps, zero_grad, (hipStream_t)stream);
@@ -1005,6 +1078,7 @@ int icamd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sh
 
 int icamd_grad_guard(float* g, long long n, const int32_t* finite_flag, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work(0.0);
   if (g == nullptr || finite_flag == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_grad_guard_launch(g, n, finite_flag, (hipStream_t)stream);
 }
@@ -1013,6 +1087,7 @@ int icamd_optim_ema(int kind, float* p, float* g, float* m, float* v, float* ema
                     float wd, float beta1, float beta2, float eps, int step, float gscale, float ema_decay,
                     const float* clip, const int32_t* finite_flag, int32_t* skipped_steps, int zero_grad, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work((22.0 + (v ? 8 : 0) + (ema ? 8 : 0)) * n);
   if (p == nullptr || g == nullptr || m == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   if ((kind == ICAMD_OPT_ADAMW || kind == ICAMD_OPT_ADAM) && v == nullptr) return ICAMD_ERR_BAD_ARG;
   return icamd_optim_ema_launch(kind, p, g, m, v, ema, (bf16_t*)shadow, n, lr, wd, beta1, beta2, eps, step, gscale,
@@ -1021,18 +1096,21 @@ int icamd_optim_ema(int kind, float* p, float* g, float* m, float* v, float* ema
 
 int icamd_lerp(float* dst, const float* src, long long n, float w, const int32_t* finite_flag, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work(12.0 * n);
   if (dst == nullptr || src == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_lerp_launch(dst, src, n, w, finite_flag, (hipStream_t)stream);
 }
 
 int icamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
   ProfScope _prof(PC_OPTIM, stream);
+  _prof.work(6.0 * n);
   if (src == nullptr || dst == nullptr || n <= 0) return ICAMD_ERR_BAD_ARG;
   return icamd_f32_to_bf16_launch(src, (bf16_t*)dst, n, (hipStream_t)stream);
 }
 
 int icamd_colsum(const void* x, int rows, int ld, int cols, float* out, int accumulate, void* stream) {
   ProfScope _prof(PC_MISC, stream);
+  _prof.work(2.0 * rows * cols);
   if (x == nullptr || out == nullptr || rows <= 0 || cols <= 0 || ld < cols) return ICAMD_ERR_BAD_ARG;
   return icamd_colsum_launch((const bf16_t*)x, rows, ld, cols, out, accumulate, (hipStream_t)stream);
 }

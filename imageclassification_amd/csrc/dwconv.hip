@@ -490,11 +490,16 @@ static int dw_rows_mode() {   // ICAMD_DWCONV_ROWS=0: the LDS tile kernels of ro
   static const int m = [] { const char* e = getenv("ICAMD_DWCONV_ROWS"); return e ? atoi(e) : 1; }();
   return m;
 }
+// The register sliding-window kernels address x / dy with 32-bit byte offsets: tensors of 4 GB and more take the LDS tile
+// kernels (64-bit addressing).  ONE predicate for the forward, the weight gradient, its block count and its workspace size.
+static bool dw_rows_usable(int N, int H, int W, int C) {
+  return dw_rows_mode() && (long long)N * H * W * C * 2 < (1ll << 32);
+}
 
 int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* addend, bf16_t* y, int N, int H,
                          int W, int C, int flip, hipStream_t s) {
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
-  if (dw_rows_mode() && (long long)N * H * W * C * 2 < (1ll << 32)) {
+  if (dw_rows_usable(N, H, W, C)) {
     const int nstrips = (W + 6) / 7;
     // threads = channel pairs x strips x images: 98 304 = 1 536 waves on every ConvNeXt-T stage at batch 256; 246 VGPRs
     // allow two waves per SIMD.  The image rows are cut in two from 28 rows up (6 halo rows are re-read per part; measured
@@ -548,7 +553,7 @@ static void dw_wgrad_rows_geometry(int N, int W, int C, int* nstrips, int* group
 }
 
 int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C) {
-  if (dw_rows_mode()) {
+  if (dw_rows_usable(N, H, W, C)) {
     int nstrips, groups, nslices; long long ib;
     dw_wgrad_rows_geometry(N, W, C, &nstrips, &groups, &nslices, &ib);
     return (int)ib;
@@ -563,7 +568,7 @@ int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C) {
 int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, int N, int H, int W, int C,
                                int accumulate, hipStream_t s) {
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
-  if (dw_rows_mode()) {
+  if (dw_rows_usable(N, H, W, C)) {
     int nstrips, groups, nslices; long long ib;
     dw_wgrad_rows_geometry(N, W, C, &nstrips, &groups, &nslices, &ib);
     if (ib * nslices >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;

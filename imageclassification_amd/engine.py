@@ -211,6 +211,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
         if per_step_host_log:
             _host_step_log(st, optimizer, log_writer, wandb_logger, use_amp, grad_norm, it, slot)
 
+    # host time the loop needed to ENQUEUE its steps (no device wait happens inside it): bench.py's host_enqueue_ms
+    train_one_epoch.last_enqueue_s = time.time() - start_time
     torch.cuda.synchronize()
     end_time = time.time()
 
@@ -289,6 +291,7 @@ def evaluate(data_loader, model, device, num_classes, use_amp=False):
     st = _state(net, device, num_classes)
     st.reset()
     nb = 0
+    eval_start = time.time()
     for batch in metric_logger.log_every(data_loader, 0, header):
         images, target = batch[0], batch[-1]
         images = images.to(device, dtype=torch.float32, non_blocking=True).contiguous()
@@ -303,6 +306,7 @@ def evaluate(data_loader, model, device, num_classes, use_amp=False):
                                          num_classes, st.loss.data_ptr(), st.finite.data_ptr(), st.acc.data_ptr(),
                                          st.counts.data_ptr(), None, 0, 0, 0, s), "step_metrics")
         nb += 1
+    evaluate.last_enqueue_s = time.time() - eval_start
     torch.cuda.synchronize()
     acc = st.acc.cpu().tolist()
     counts = st.counts.cpu().tolist()

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libicamd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ERRORS = {1: "ICAMD_ERR_BAD_ARG", 2: "ICAMD_ERR_UNSUPPORTED", 3: "ICAMD_ERR_WORKSPACE", 4: "ICAMD_ERR_LAUNCH"}
 
 
@@ -137,7 +137,7 @@ _SIGNATURES = {
     "icamd_broadcast_launch": (c_int, [_P, _P, c_longlong, c_int, c_int, _P]),
     "icamd_prof_enable": (c_int, [c_int]),
     "icamd_prof_classes": (c_int, []),
-    "icamd_prof_collect": (c_int, [POINTER(c_double), POINTER(c_longlong), c_int]),
+    "icamd_prof_collect": (c_int, [POINTER(c_double), POINTER(c_longlong), POINTER(c_double), POINTER(c_double), c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -185,14 +185,20 @@ def require_gpu():
 
 
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_finalize", "bn_apply", "bn_bwd", "pool", "pack", "loss",
-                "optimizer", "misc")
+                "optimizer", "misc", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "elementwise", "dwconv")
 
 
-def prof_collect():
-    """{class: (elapsed_ms, calls)} accumulated since the last call (HIP events on the launch stream)."""
+def prof_collect(work=False):
+    """{class: (elapsed_ms, calls)} accumulated since the last call (HIP events on the launch stream); with work=True
+    {class: (elapsed_ms, calls, algorithmic_bytes, algorithmic_flops)} (include/icamd.h: icamd_prof_collect)."""
     lib = load()
     n = lib.icamd_prof_classes()
+    assert n == len(PROF_CLASSES), (n, len(PROF_CLASSES))
     ms = (c_double * n)()
     calls = (c_longlong * n)()
-    check(lib.icamd_prof_collect(ms, calls, n), "prof_collect")
+    nbytes = (c_double * n)()
+    flops = (c_double * n)()
+    check(lib.icamd_prof_collect(ms, calls, nbytes, flops, n), "prof_collect")
+    if work:
+        return {PROF_CLASSES[i]: (ms[i], calls[i], nbytes[i], flops[i]) for i in range(n)}
     return {PROF_CLASSES[i]: (ms[i], calls[i]) for i in range(n)}

@@ -387,10 +387,13 @@ int icamd_broadcast_launch(void* comm, void* buf, long long count, int dtype, in
 
 /* ---- measurement aid (bench.py): HIP-event timing of every entry point on its launch stream ----------------
  * classes: 0 conv fwd, 1 conv dgrad, 2 conv wgrad(+slab reduce), 3 bn finalize, 4 bn apply, 5 bn bwd, 6 pooling,
- * 7 input pack, 8 loss/metrics, 9 optimizer (+filter transpose), 10 misc.  collect() adds elapsed ms / calls. */
+ * 7 input pack, 8 loss/metrics, 9 optimizer (+filter transpose), 10 misc, 11 attention fwd, 12 attention bwd, 13 LayerNorm fwd,
+ * 14 LayerNorm bwd, 15 elementwise (GELU, layer scale), 16 depthwise 7x7.  collect() adds, per class, elapsed ms, calls and
+ * (ABI 4; either array may be NULL) the ALGORITHMIC bytes and flops of the calls: every operand tensor read once and every
+ * result written once at its stored width (two-pass kernels as their two passes), flops = 2 x multiply-adds. */
 int icamd_prof_enable(int on);
 int icamd_prof_classes(void);
-int icamd_prof_collect(double* ms, long long* calls, int n);
+int icamd_prof_collect(double* ms, long long* calls, double* bytes, double* flops, int n);
 
 #ifdef __cplusplus
 }

@@ -265,3 +265,21 @@ def time_cpu_training(arch="resnet50", batch=32, hw=224, num_classes=1000, warmu
                         wd_schedule_values=wd, num_training_steps_per_epoch=steps, num_classes=num_classes)
     dt = time.time() - t0
     return batch * steps / dt, torch.get_num_threads(), dt / steps
+
+
+def time_cpu_eval(arch="resnet50", batch=32, hw=224, num_classes=1000, warmup=1, steps=3, threads=None, seed=88):
+    """CPU baseline for `bench.py --mode eval`: the restated evaluate loop (reference engine.py:145-225: eval-mode forward,
+    cross-entropy, top-1, per-class counts) on synthetic data, fp32.  Returns (images_per_second, threads_used, seconds_per_batch)."""
+    from .resnet_ref import ResNetRef
+    if threads:
+        torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    model = ResNetRef(arch, num_classes)
+    data = [(torch.randn(batch, 3, hw, hw, generator=g), torch.randint(0, num_classes, (batch,), generator=g)) for _ in range(2)]
+    with torch.no_grad():
+        if warmup:
+            evaluate_ref([data[i % 2] for i in range(warmup)], model, num_classes)
+        t0 = time.time()
+        evaluate_ref([data[i % 2] for i in range(steps)], model, num_classes)
+        dt = time.time() - t0
+    return batch * steps / dt, torch.get_num_threads(), dt / steps

@@ -284,7 +284,11 @@ def bf16_close(a, b, ulps=2.0, atol_rms=2e-3, max_frac=0.0):
     mag = torch.maximum(a.abs(), b.abs()).clamp_min(1e-30)
     ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
     rms = float(torch.sqrt((b.double() ** 2).mean()))
-    bad = ((a - b).abs() > ulps * ulp + atol_rms * rms)
+    # "not within the bound" (rather than "beyond it"): a NaN / Inf in either tensor compares False and counts as bad
+    # (an Inf makes its own bound infinite, hence the explicit finiteness term)
+    bad = ~((a - b).abs() <= ulps * ulp + atol_rms * rms) | ~torch.isfinite(a) | ~torch.isfinite(b)
+    if max_frac <= 0.0:
+        return not bool(bad.any())
     return bool(float(bad.float().mean()) <= max_frac)
 
 

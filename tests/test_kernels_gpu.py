@@ -1471,6 +1471,9 @@ def test_layernorm_bwd_bits_do_not_depend_on_a_second_stream(lib):
     ln()
     sync()
     ref = (dbet.clone(), dgam.clone(), dx.clone())
+    # round 4: the VALUES at model size, against the oracle (torch's own layer_norm backward on the CPU), alone and while the
+    # second stream is busy -- not only run-to-run stability
+    rdx, rdg, rdb = R.layernorm_bwd(dy.float().cpu(), x.float().cpu(), gamma.cpu(), 1e-6)
     for with_side in (False, True):
         for _ in range(6):
             if with_side:
@@ -1480,6 +1483,8 @@ def test_layernorm_bwd_bits_do_not_depend_on_a_second_stream(lib):
             ln()
             sync()
             assert torch.equal(dbet, ref[0]) and torch.equal(dgam, ref[1]) and torch.equal(dx, ref[2]), with_side
+            assert R.rel_l2(dbet.cpu(), rdb) <= 1e-4 and R.rel_l2(dgam.cpu(), rdg) <= 1e-4, (with_side, R.rel_l2(dbet.cpu(), rdb))
+    assert R.rel_l2(dx.float().cpu(), rdx) <= 1e-3
 
 
 @pytest.mark.parametrize("which", ["layernorm_bwd_c96", "layernorm_bwd_c384", "layernorm_bwd_c768", "layerscale_bwd", "colsum_rows",
@@ -1514,6 +1519,8 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
         def run():
             assert lib.icamd_layernorm_bwd(hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), None, hip.ptr(outs[0]),
                                            hip.ptr(outs[1]), hip.ptr(outs[2]), rows, C, 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
+        _, rdg, rdb = R.layernorm_bwd(dy.float().cpu(), x.float().cpu(), gamma.cpu(), 1e-6)
+        oracle = {1: (rdg, 1e-4), 2: (rdb, 1e-4)}
     elif which == "layerscale_bwd":
         rows, C, rpi = 200704, 192, 784
         dout = (torch.randn(rows, C, device=DEV, generator=g) * 1e-3).bfloat16()
@@ -1527,6 +1534,9 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
         def run():
             assert lib.icamd_layerscale_bwd(hip.ptr(dout), hip.ptr(z), hip.ptr(gamma), hip.ptr(keep), hip.ptr(outs[0]), hip.ptr(outs[1]),
                                             rows, C, rpi, 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
+        _, rdgam = R.layerscale_bwd(dout.float().cpu().reshape(rows // rpi, rpi, C), z.float().cpu().reshape(rows // rpi, rpi, C),
+                                    gamma.cpu(), keep.cpu())
+        oracle = {1: (rdgam, 1e-4)}
     elif which == "colsum_rows":
         rows, C = 200704, 192
         x = (torch.randn(rows, C, device=DEV, generator=g) * 1e-3).bfloat16()
@@ -1536,6 +1546,7 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
 
         def run():
             assert lib.icamd_colsum_rows(hip.ptr(x), rows, C, C, hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
+        oracle = {0: (x.float().cpu().double().sum(0).float(), 1e-5)}
     else:
         N, H, W, C = 128, 28, 28, 192
         x = torch.randn(N, H, W, C, device=DEV, generator=g).bfloat16()
@@ -1547,6 +1558,8 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
         def run():
             assert lib.icamd_dwconv7_wgrad(hip.ptr(x), hip.ptr(dy), hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, N, H, W, C,
                                            main.cuda_stream) == 0
+        _, rdw = R.dwconv7_bwd(x.float().cpu(), torch.zeros(C, 7, 7), dy.float().cpu())
+        oracle = {0: (rdw, 1e-4)}
 
     run()
     sync()
@@ -1561,6 +1574,9 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
             sync()
             for o, r in zip(outs, ref):
                 assert torch.equal(o, r), (which, with_side)
+            # round 4: the sums themselves against the oracle at model size, second stream busy or not
+            for i, (want, tol) in oracle.items():
+                assert R.rel_l2(outs[i].cpu().reshape(want.shape), want) <= tol, (which, with_side, i)
 
 
 @pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96), (3, 28, 28, 64),

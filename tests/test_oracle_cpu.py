@@ -507,3 +507,37 @@ def test_gelu_constants_of_the_hip_kernels_hold_their_stated_error():
     phi = np.exp2(z.astype(np.float64) ** 2 * -0.72134752044448170 - 1.3257480647361593)
     grad_ref = ndtr(z.astype(np.float64)) + z.astype(np.float64) * np.exp(-0.5 * z.astype(np.float64) ** 2) / math.sqrt(2 * math.pi)
     assert np.abs(cdf + z * phi - grad_ref).max() <= 3e-6
+
+
+def test_bf16_close_rejects_non_finite_values():
+    """the elementwise comparator of the kernel tests must fail on a NaN / Inf in the tested tensor (a comparison
+    `|a-b| > bound` is False for NaN and let it through), with and without an allowed outlier share."""
+    from oracle import ops_ref as R
+    b = R.bf16_round(torch.randn(4096))
+    assert R.bf16_close(b.clone(), b) and R.bf16_close(b.clone(), b, max_frac=1e-3)
+    for poison in (float("nan"), float("inf"), -float("inf")):
+        a = b.clone()
+        a[17] = poison
+        assert not R.bf16_close(a, b)
+        assert not R.bf16_close(a, b, max_frac=1e-6)
+        assert not R.bf16_close(b, a)            # a poisoned oracle value must not pass either
+    a = b.clone()
+    a[5] += 1.0                                  # one finite outlier: rejected at max_frac 0, accepted within the share
+    assert not R.bf16_close(a, b) and R.bf16_close(a, b, max_frac=1e-3)
+
+
+def test_isa_lint_flags_the_packed_fp32_op_sel_form(tmp_path):
+    """tools/isa_lint.py (run by csrc/build.sh): the instruction form behind round 3's wrong LayerNorm column sums is reported,
+    its harmless relatives (no op_sel, op_sel_hi only, v_pk_mov_b32) are not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    s = tmp_path / "k.s"
+    s.write_text("_Z1kv:\n\tv_pk_add_f32 v[68:69], v[68:69], v[30:31] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                 "\tv_pk_fma_f32 v[6:7], v[20:21], v[18:19], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n"
+                 "\tv_pk_add_f32 v[2:3], v[2:3], v[4:5]\n\tv_pk_mul_f32 v[2:3], v[2:3], v[4:5] op_sel_hi:[1,0]\n"
+                 "\tv_pk_mov_b32 v[24:25], v[20:21], v[20:21] op_sel:[1,0]\n")
+    hits, n = lint.lint(str(s))
+    assert n == 4 and [h[0] for h in hits] == [2, 3] and all(h[1] == "_Z1kv" for h in hits)
+    assert lint.main([str(s)]) == 1

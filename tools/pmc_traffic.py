@@ -6,7 +6,7 @@ section).  Sanity anchor: the BatchNorm kernels' result must equal their algorit
 The summary is stamped with the workload and with bench.kernel_source_hash() of the tree it is run from (run it from the
 snapshot that was profiled): bench.py reports `roofline.traffic` from it only while both match.
 
-Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <steps_in_run> <out.json> [arch] [batch]"""
+Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <steps_in_run> <out.json> [arch] [batch] [train|eval]"""
 import json
 import os
 import re
@@ -37,6 +37,7 @@ def main():
     fetch_db, write_db, steps, out_path = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     arch = sys.argv[5] if len(sys.argv) > 5 else "resnet50"
     batch = int(sys.argv[6]) if len(sys.argv) > 6 else 256
+    mode = sys.argv[7] if len(sys.argv) > 7 else "train"
     from bench import kernel_source_hash
     # units: rocprofv3's derived FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 correction x2 on FETCH_SIZE (guide, HBM section)
     fetch = per_kernel(fetch_db, "FETCH_SIZE")
@@ -56,7 +57,7 @@ def main():
     doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) via tools/pmc_traffic.py; %d steps in the "
                      "profiled run; FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
                      "bytes" % steps,
-           "workload": {"arch": arch, "batch": batch}, "kernel_source_hash": kernel_source_hash(),
+           "workload": {"arch": arch, "batch": batch, "mode": mode}, "kernel_source_hash": kernel_source_hash(),
            "kernels": kernels, "total_fetch_GB_per_step": tf, "total_write_GB_per_step": tw}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1)
