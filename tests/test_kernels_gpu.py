@@ -149,9 +149,35 @@ LARGE_POINTWISE = [
 ]
 
 
+def _memo(key, fn):
+    """CPU-oracle results of the large pointwise cases, shared between this process and the forced-route child processes that
+    re-run the same cases through other kernels (the oracle of LARGE_POINTWISE costs ~25 s per pass on the GPU box's host):
+    keyed by the case and the oracle source's mtime, stored under the system temp directory."""
+    import hashlib
+    import tempfile
+    stamp = os.path.getmtime(R.__file__)
+    name = hashlib.sha1(repr((key, stamp)).encode()).hexdigest()[:20]
+    path = os.path.join(tempfile.gettempdir(), "icamd_oracle_memo_%d" % os.getuid(), name + ".pt")
+    if os.path.exists(path):
+        try:
+            return torch.load(path)
+        except Exception:
+            pass
+    val = fn()
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".%d.tmp" % os.getpid()
+        torch.save(val, tmp)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return val
+
+
 def _run_large_pointwise(lib, cases):
     hip = _hip()
     for (N, H, W, Cin, Cout) in cases:
+        case = (N, H, W, Cin, Cout)
         d = hip.conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0)
         x = rnd_bf16(N, H, W, Cin, seed=11)
         w = rnd_bf16(Cout, 1, 1, Cin, scale=(1.0 / Cin) ** 0.5, seed=12)
@@ -159,7 +185,8 @@ def _run_large_pointwise(lib, cases):
         addend = rnd_bf16(N, H, W, Cout, seed=14)
         xd, wd = to_dev_bf16(x), to_dev_bf16(w)
         for use_extra in (False, True):
-            ref = R.conv2d_fwd(x, w, 1, 0, bias if use_extra else None, addend if use_extra else None)
+            ref = _memo(("pw_fwd", case, use_extra),
+                        lambda: R.conv2d_fwd(x, w, 1, 0, bias if use_extra else None, addend if use_extra else None))
             y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
             bd = bias.to(DEV) if use_extra else None
             ad = to_dev_bf16(addend) if use_extra else None
@@ -179,7 +206,7 @@ def _run_large_pointwise(lib, cases):
                                     hip.stream_ptr()) == 0
         sync()
         got = y.float().cpu()
-        assert R.rel_l2(got, R.conv2d_fwd(x, w, 1, 0, None, None)) <= 1e-3
+        assert R.rel_l2(got, _memo(("pw_fwd", case, False), lambda: R.conv2d_fwd(x, w, 1, 0, None, None))) <= 1e-3
         s1, s2 = R.conv2d_stats(got)
         st = stats.double().cpu()
         assert torch.isfinite(st).all()
@@ -190,7 +217,7 @@ def _run_large_pointwise(lib, cases):
         w_t = w.permute(3, 1, 2, 0).contiguous()
         dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w_t)
         for use_add in (False, True):
-            ref = R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in if use_add else None)
+            ref = _memo(("pw_dgrad", case, use_add), lambda: R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in if use_add else None))
             dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
             ad = to_dev_bf16(add_in) if use_add else None
             rc = lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), None,
@@ -204,7 +231,7 @@ def _run_large_pointwise(lib, cases):
         if Cin % 64 == 0:   # addend counted only where its ReLU-mask bit is set (residual shortcut)
             mask = torch.rand(N, H, W, Cin, generator=torch.Generator().manual_seed(17)) > 0.4
             bits = (mask.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
-            ref = R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in * mask)
+            ref = _memo(("pw_dgrad_mask", case), lambda: R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in * mask))
             dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
             ad, bd = to_dev_bf16(add_in), bits.to(DEV)
             assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), hip.ptr(bd),
@@ -1559,7 +1586,7 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
             assert lib.icamd_dwconv7_wgrad(hip.ptr(x), hip.ptr(dy), hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, N, H, W, C,
                                            main.cuda_stream) == 0
         _, rdw = R.dwconv7_bwd(x.float().cpu(), torch.zeros(C, 7, 7), dy.float().cpu())
-        oracle = {0: (rdw, 1e-4)}
+        oracle = {0: (rdw.permute(1, 2, 0).contiguous(), 1e-4)}    # the kernel's layout is [7][7][C]
 
     run()
     sync()

@@ -224,68 +224,6 @@ def test_resnet50_whole_network_parity_well_conditioned(gamma_last):
         assert e <= 3.0 * max(n, 5e-3), (name, e, n)
 
 
-def test_resnet50_loss_curve_tracks_oracle():
-    """north_star: "loss curve matching CPU reference to 1e-3".  24 optimizer steps of the reference recipe (AdamW, label
-    smoothing 0.1, lr warming up linearly from 0 as the reference's cosine_scheduler does, wd 5e-4; /root/reference/
-    engine.py:46-77) on four 32-image batches cycled, from identical timm-default weights:
-      * the CPU oracle with ITS OWN gradients (torch autograd, bf16 rounding points, torch.optim.AdamW),
-      * the same in fp64 (how far two correct implementations drift apart: the yardstick),
-      * imageclassification_amd.engine.train_one_epoch on the GPU.
-    The loss falls from 2.38 to ~0.54 as the batches are memorised.  ONE tolerance rule, for every step i: the HIP loss is
-    within max(1e-3, 3 x D_i) (relative) of the oracle's, D_i = the largest distance the oracle's own fp64 twin has shown up
-    to step i -- once two correct trajectories have parted by d, later steps inherit it; and at least 20 of the 24 steps
-    must sit within the plain 1e-3.  The table and the step at which each pair first parts by more than 1e-3 are printed.
-    (Measured on MI355X in round 2: HIP within 6.4e-4 for 21 steps, 1.2e-3 at step 21 where the fp64 twin had already shown
-    7.3e-4; the same oracle code on two different host CPUs differs by 4e-4 at step 2 already.)"""
-    import copy
-    from imageclassification_amd.engine import LOG_RING, train_one_epoch
-    from imageclassification_amd.mixup import LabelSmoothingCrossEntropy
-    from imageclassification_amd.optim_factory import create_optimizer
-    from imageclassification_amd.utils import NativeScalerWithGradNormCount
-    from oracle import engine_ref as E
-    C, B, HW, steps, nb = 10, 32, 128, 24, 4
-    ref, net = _timm_default_pair("resnet50", C)
-    ref64 = copy.deepcopy(ref).double()
-    g = torch.Generator().manual_seed(5)
-    data = [(torch.randn(B, 3, HW, HW, generator=g), torch.randint(0, C, (B,), generator=g)) for _ in range(nb)]
-    loader = [data[i % nb] for i in range(steps)]
-    lr = [1e-3 * i / 24 for i in range(steps)]
-    wd = [5e-4] * steps
-
-    def oracle_run(model, params):
-        opt = torch.optim.AdamW([{"params": list(params), "weight_decay": 5e-4}], lr=1e-3, weight_decay=0.0)
-        tr = []
-        E.train_one_epoch_ref(model, E.LabelSmoothingCrossEntropyRef(0.1), [(x.clone(), t.clone()) for x, t in loader], opt,
-                              lr_schedule_values=lr, wd_schedule_values=wd, num_training_steps_per_epoch=steps,
-                              num_classes=C, trace=tr)
-        return [t["loss"] for t in tr]
-
-    l_ref = oracle_run(ref, ref.parameters())
-    l_64 = oracle_run(_As64(ref64), ref64.parameters())
-    opt = create_optimizer("adamw", 1e-3, 5e-4, net)
-    stats = train_one_epoch(net, LabelSmoothingCrossEntropy(0.1), loader, opt, torch.device("cuda"), 0,
-                            NativeScalerWithGradNormCount(), None, None, None, start_steps=0, lr_schedule_values=lr,
-                            wd_schedule_values=wd, num_training_steps_per_epoch=steps, update_freq=1, use_amp=False,
-                            num_classes=C)
-    st = list(net._step_states.values())[0]
-    l_hip = st.log[:steps].cpu().tolist()
-    d_hip = [abs(a - b) / abs(b) for a, b in zip(l_hip, l_ref)]
-    d_self = [abs(a - b) / abs(b) for a, b in zip(l_64, l_ref)]
-    print("step   oracle      oracle-fp64  HIP         |HIP-oracle|/oracle  |fp64-oracle|/oracle")
-    for i in range(steps):
-        print(f"{i:4d}   {l_ref[i]:.6f}    {l_64[i]:.6f}     {l_hip[i]:.6f}    {d_hip[i]:.2e}            {d_self[i]:.2e}")
-    part = lambda d: next((i for i, v in enumerate(d) if v > 1e-3), None)   # noqa: E731
-    print(f"first step parted by > 1e-3: HIP {part(d_hip)}, oracle fp64 {part(d_self)} (None = never in {steps} steps)")
-    assert l_ref[-1] < 0.35 * l_ref[0]                      # a real curve: the loss moved
-    assert abs(stats["loss"] - sum(l_ref) / steps) <= 1e-3 * sum(l_ref) / steps
-    assert opt.steps_taken == steps
-    drift = 0.0
-    for i in range(steps):
-        drift = max(drift, d_self[i])
-        assert d_hip[i] <= max(1e-3, 3.0 * drift), (i, d_hip[i], drift)
-    assert sum(1 for v in d_hip if v <= 1e-3) >= 20, d_hip
-
-
 @pytest.mark.parametrize("arch,B,HW,tol", [("resnet18", 8, 64, 3e-2), ("resnet50", 4, 96, 8e-2)])
 def test_backward_teacher_forced_is_tight(arch, B, HW, tol):
     """Wiring proof without the chaos: every tensor the backward pass reads (conv outputs, activations, pooling
