@@ -203,6 +203,18 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
     return icamd_pw_resident_launch(g, (hipStream_t)stream);
   }
+  // evaluate()'s BatchNorm-folded forward (bias = the folded shift, optional residual addend, ReLU): the same register-resident
+  // kernel with the inference epilogue (round 4; these launches ran on conv_igemm's single-stage tiles before)
+  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (bias != nullptr || relu) && stats == nullptr &&
+      gelu_out == nullptr && !gelu_inplace && icamd_pw_resident_epi_wanted() &&
+      icamd_pw_resident_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin, addend != nullptr)) {
+    PwResidentParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.bias = bias; g.relu = relu;
+    g.addend = (const bf16_t*)addend;
+    g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
+    return icamd_pw_resident_launch(g, (hipStream_t)stream);
+  }
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && addend == nullptr && !relu && stats == nullptr &&
       icamd_pw_resident_ext_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
     PwResidentParams g;

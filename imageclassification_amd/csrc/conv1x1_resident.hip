@@ -35,7 +35,9 @@ namespace {
 // landing under the MFMAs), the mask words are one 64-bit load per row, and the store pass -- which already holds 8 channels
 // of one row per lane -- reads the matching 16 B of y back and keeps the sums in registers across tiles.  bn_bwd_reduce (a full
 // read of dout and y) disappears for that BatchNorm; this kernel reads y once instead.
-template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false, bool BNR = false>
+// EPI (round 4): the inference epilogue of evaluate()'s BatchNorm-folded forward (engine.py:145-225): + bias[n] in fp32, + addend
+// (the ADD patch), ReLU, ONE rounding -- the arithmetic of conv_igemm's fused epilogue, which these launches used to run on.
+template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false, bool BNR = false, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
-  f32x4 bias4[EXT ? NF : 1];      // MFMA layout: a lane owns channels n0 + j*16 + 4*fq .. +3 of its rows
-  if constexpr (EXT) {
+  f32x4 bias4[(EXT || EPI) ? NF : 1];      // MFMA layout: a lane owns channels n0 + j*16 + 4*fq .. +3 of its rows
+  if constexpr (EXT || EPI) {
 #pragma unroll
     for (int j = 0; j < NF; ++j)
       bias4[j] = p.bias != nullptr ? *(const f32x4*)(p.bias + n0 + j * 16 + 4 * fq) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
 #pragma unroll
           for (int j = 0; j < NF; ++j) {
             f32x4 v = acc[j][i];
-            if constexpr (EXT) v += bias4[j];
+            if constexpr (EXT || EPI) v += bias4[j];
             if constexpr (ADD) {
               if (has_add) {
                 constexpr int LPRA = EROW / 16;
@@ -236,6 +238,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
                 v[1] += (bb & 2u) ? bf16_hi(a[0]) : 0.f;
                 v[2] += (bb & 4u) ? bf16_lo(a[1]) : 0.f;
                 v[3] += (bb & 8u) ? bf16_hi(a[1]) : 0.f;
+              }
+            }
+            if constexpr (EPI) {
+              if (p.relu) {   // as conv_igemm's epilogue and torch.relu: NaN stays NaN
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] < 0.f) ? 0.f : v[e];
               }
             }
             if constexpr (BNR) {   // g = d(block output) * [block output > 0]
@@ -369,6 +377,15 @@ bool pick(int N, int K, Config* c) {
 
 template <int KS, int NF, int MF, int WN>
 int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
+  if (p.bias != nullptr || p.relu) {   // inference epilogue (never with statistics)
+    if (p.stats != nullptr) return ICAMD_ERR_UNSUPPORTED;
+    if (p.addend != nullptr) {
+      if constexpr (KS == 8 && NF == 2 && WN == 4) return ICAMD_ERR_UNSUPPORTED;
+      else hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true, false, false, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    } else
+      hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return icamd_launch_status();
+  }
   if (p.addend != nullptr) {
     // (K = 256 with 32-channel waves: activation buffers + addend patches exceed the 80 KB of two workgroups per CU)
     if constexpr (KS == 8 && NF == 2 && WN == 4) return ICAMD_ERR_UNSUPPORTED;
@@ -440,6 +457,11 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   S = (p.M + rows - 1) / rows;
   hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
   return icamd_launch_status();
+}
+
+bool icamd_pw_resident_epi_wanted() {
+  static const int on = [] { const char* e = getenv("ICAMD_PW_RESIDENT_EPI"); return e ? atoi(e) : 1; }();
+  return on != 0 && mode() != 0;
 }
 
 bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend) {

@@ -102,11 +102,13 @@ struct PwResidentParams {
   float* bn_part;
   int lda, Ktrue;                 // 0: K
   const float* bias;              // optional [N]
+  int relu;                       // inference epilogue (EPI instantiations): out = relu(acc + bias + addend)
   bf16_t* gelu_out;               // optional second output: gelu(rounded out)
   int gelu_inplace;               // out itself receives gelu(rounded result)
   const bf16_t* gelu_z;           // optional [M][N]: out = rounded result * gelu'(gelu_z)
 };
 bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend = false);
+bool icamd_pw_resident_epi_wanted();   // ICAMD_PW_RESIDENT_EPI=0: evaluate()'s pointwise layers stay on conv_igemm (A/B, tests)
 // the ext form: plain pointwise problems with K = 96 (bias / GELU epilogues allowed, no addend / statistics)
 bool icamd_pw_resident_ext_wanted(long long M, int N, int K);
 int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream);

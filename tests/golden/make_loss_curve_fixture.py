@@ -1,8 +1,10 @@
-"""CPU side of tests/test_zz_loss_curve_gpu.py: the oracle's own 24-step loss curve (fp32 accumulation, bf16 rounding points)
-and its fp64 twin, ~5 minutes of host work.  Run as a child process that tests/conftest.py starts when the GPU session is
-collected, so that it overlaps with the rest of the suite instead of holding the GPU box for half of the driver's time limit
-(round 3: 364 s of a 709 s suite).  Test infrastructure; no GPU, no product code.
-Usage: python tests/_loss_curve_oracle.py <out.json> [threads]"""
+"""Generates tests/golden/loss_curve_resnet50.json: the CPU oracle's own 24-step loss curve of ResNet-50 (fp32 accumulation, bf16
+rounding points; oracle/engine_ref.py + oracle/resnet_ref.py) and the curve of its fp64 twin (the drift yardstick), ~6 minutes of
+host work on 8 cores.  Until round 3 tests/test_model_gpu.py computed both inside the GPU test: 364 s of the driver's 900 s limit,
+spent on the GPU box's host.  The curves are data (24 + 24 numbers + provenance); the GPU test replays the same seeded batches
+through the HIP engine and compares; tests/test_oracle_cpu.py re-runs the first steps with the live oracle and pins the file to it.
+Test infrastructure; no GPU, no product code.
+Usage: python tests/golden/make_loss_curve_fixture.py [out.json] [threads]"""
 import copy
 import json
 import os
@@ -11,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import engine_ref as E  # noqa: E402
 from oracle.resnet_ref import ResNetRef  # noqa: E402
 
@@ -53,7 +55,7 @@ def oracle_run(model, params, loader):
 
 
 def main():
-    out = sys.argv[1]
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "loss_curve_resnet50.json")
     if len(sys.argv) > 2:
         torch.set_num_threads(int(sys.argv[2]))
     t0 = time.time()
@@ -67,7 +69,11 @@ def main():
         l_64 = oracle_run(_As64(ref64), ref64.parameters(), loader)
     tmp = out + ".tmp"
     with open(tmp, "w") as f:
-        json.dump({"oracle": l_ref, "oracle_fp64": l_64, "seconds": time.time() - t0, "threads": torch.get_num_threads()}, f)
+        json.dump({"what": "ResNet-50 (timm default init, seed 0), 10 classes, 24 AdamW steps on four cycled 32-image 128x128 batches "
+                           "(generator seed 5), label smoothing 0.1, lr 1e-3 * i / 24, wd 5e-4: per-step loss of the CPU oracle and of "
+                           "its fp64 twin", "generator": "tests/golden/make_loss_curve_fixture.py",
+                   "torch": torch.__version__, "cpu": open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
+                   "oracle": l_ref, "oracle_fp64": l_64, "seconds": time.time() - t0, "threads": torch.get_num_threads()}, f, indent=1)
     os.replace(tmp, out)
 
 

@@ -66,6 +66,30 @@ def test_train_one_epoch_matches_oracle_loop():
     assert int(counts[0].sum()) == round(stats["class_acc"] * B * 4)
 
 
+def test_config0_at_its_own_size_one_step_matches_oracle():
+    """BASELINE configs[0] at ITS OWN size: ResNet-18, 2 classes, batch 32 at 224 x 224 (the reference's
+    cat/dog ImageFolder case, /root/reference/train.py:36 --input_size 224, README.md:19-21), one optimizer step of the reference
+    recipe through train_one_epoch and an evaluate() pass over two batches -- 32 and a ragged 19 -- against the oracle loop."""
+    from imageclassification_amd.engine import evaluate
+    C, B, HW = 2, 32, 224
+    ref, net, opt, opt_ref = _setup(C, seed=9)
+    data = _loader(1, B, C, seed=31, hw=HW)
+    rstats = E.train_one_epoch_ref(ref, E.LabelSmoothingCrossEntropyRef(0.1), [(x.clone(), y.clone()) for x, y in data], opt_ref,
+                                   lr_schedule_values=[1e-6], wd_schedule_values=[5e-4], num_training_steps_per_epoch=1,
+                                   num_classes=C)
+    stats = _train(net, opt, data, C)
+    assert list(stats) == ["loss", "class_acc"]
+    assert abs(stats["loss"] - rstats["loss"]) <= 5e-3 * rstats["loss"], (stats, rstats)
+    assert abs(stats["class_acc"] - rstats["class_acc"]) <= 2.0 / B
+    assert opt.steps_taken == 1 and net.num_batches_tracked == 1
+    g = torch.Generator().manual_seed(32)
+    val = [(torch.randn(n, 3, HW, HW, generator=g), torch.randint(0, C, (n,), generator=g)) for n in (B, 19)]
+    rev = E.evaluate_ref([(x.clone(), y.clone()) for x, y in val], ref, C)
+    ev = evaluate(val, net, DEV, C)
+    assert set(ev) == set(rev) and {"loss", "acc1", "avg_precision", "avg_recall", "precision_1", "recall_1"} <= set(ev)
+    assert abs(ev["loss"] - rev["loss"]) <= 5e-3 * rev["loss"] and abs(ev["acc1"] - rev["acc1"]) <= 100.0 * 2 / (B + 19)
+
+
 def test_non_finite_loss_skips_the_step_on_device():
     C, B = 10, 8
     _, net, opt, _ = _setup(C, seed=1)

@@ -262,6 +262,11 @@ def test_pointwise_register_resident_filter_every_shape():
         "                             (64, 28, 28, 64, 256), (32, 56, 56, 256, 64)])\n"
         "for case in [(2, 12, 12, 256, 128, 1, 1, 0), (1, 8, 8, 512, 256, 1, 1, 0), (3, 7, 7, 512, 256, 1, 1, 0)]:\n"
         "    T.test_conv_dgrad_addend_on_even_grid(lib, case)\n"
+        "# round 4: the inference epilogue (bias + residual + ReLU) of every instantiated shape (evaluate()'s folded forward)\n"
+        "for case in [(2, 9, 9, 64, 256, 1, 1, 0), (3, 7, 5, 64, 64, 1, 1, 0), (2, 10, 10, 128, 512, 1, 1, 0),\n"
+        "             (2, 8, 8, 256, 1024, 1, 1, 0), (1, 13, 11, 256, 128, 1, 1, 0), (2, 9, 7, 256, 64, 1, 1, 0),\n"
+        "             (2, 6, 6, 512, 2048, 1, 1, 0), (1, 8, 8, 512, 128, 1, 1, 0)]:\n"
+        "    T.test_conv_fwd_act_and_bn_fold(lib, case)\n"
         "print('forced-ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, ICAMD_PW_RESIDENT="2")
@@ -296,7 +301,10 @@ def test_pointwise_large_tile_gemm_forced_small_k(tn):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 1, 1, 0), (3, 9, 7, 64, 128, 3, 1, 1), (2, 16, 16, 8, 64, 7, 2, 3),
-                                  (2, 14, 14, 256, 512, 1, 2, 0)])
+                                  (2, 14, 14, 256, 512, 1, 2, 0),
+                                  # large enough for the register-resident pointwise kernel's inference form by its own routing
+                                  # (several tiles per persistent workgroup, ragged last tile): 64 -> 256 and 256 -> 64 at 56 x 56
+                                  (84, 56, 56, 64, 256, 1, 1, 0), (86, 56, 55, 256, 64, 1, 1, 0)])
 def test_conv_fwd_act_and_bn_fold(lib, case):
     """Inference epilogue: y = relu(conv(x, w_folded) + shift + residual) with w_folded/shift from icamd_bn_fold_filters,
     against eval-mode BatchNorm applied to the fp32 convolution of the same bf16 inputs (oracle)."""

@@ -541,3 +541,31 @@ def test_isa_lint_flags_the_packed_fp32_op_sel_form(tmp_path):
     hits, n = lint.lint(str(s))
     assert n == 4 and [h[0] for h in hits] == [2, 3] and all(h[1] == "_Z1kv" for h in hits)
     assert lint.main([str(s)]) == 1
+
+
+def test_loss_curve_fixture_is_the_live_oracles_curve():
+    """tests/golden/loss_curve_resnet50.json (the oracle trajectories the GPU loss-curve test compares with) against the live
+    oracle: the first two steps re-run here (ResNet-50, batch 32, 128 x 128: ~20 s) must reproduce the stored losses -- step 0
+    depends on the forward only (1e-5), step 1 on one full backward + AdamW step with lr = 1e-3 / 24 (1e-4: a different host CPU
+    re-associates the convolutions).  A changed oracle, init, seed or recipe shows here, on the CPU, not as a GPU mystery."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_loss_curve_fixture", os.path.join(HERE, "golden", "make_loss_curve_fixture.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    doc = json.load(open(os.path.join(HERE, "golden", "loss_curve_resnet50.json")))
+    assert len(doc["oracle"]) == gen.STEPS == 24 and len(doc["oracle_fp64"]) == 24
+    assert doc["oracle"][-1] < 0.35 * doc["oracle"][0]
+    ref = gen.reference_model()
+    loader = gen.batches()[:2]
+    lr, wd = gen.schedules()
+    opt = torch.optim.AdamW([{"params": list(ref.parameters()), "weight_decay": 5e-4}], lr=1e-3, weight_decay=0.0)
+    from oracle import engine_ref as E
+    tr = []
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        E.train_one_epoch_ref(ref, E.LabelSmoothingCrossEntropyRef(0.1), [(x.clone(), t.clone()) for x, t in loader], opt,
+                              lr_schedule_values=lr, wd_schedule_values=wd, num_training_steps_per_epoch=2, num_classes=gen.C, trace=tr)
+    assert abs(tr[0]["loss"] - doc["oracle"][0]) <= 1e-5 * doc["oracle"][0], (tr[0]["loss"], doc["oracle"][0])
+    assert abs(tr[1]["loss"] - doc["oracle"][1]) <= 1e-4 * doc["oracle"][1], (tr[1]["loss"], doc["oracle"][1])
+    assert abs(doc["oracle_fp64"][0] - doc["oracle"][0]) <= 1e-3 * doc["oracle"][0]
