@@ -324,7 +324,11 @@ def test_conv_fwd_act_and_bn_fold(lib, case):
                                      k * k * Cin, hip.ptr(wf), hip.ptr(shift), hip.stream_ptr()) == 0
     sync()
     scale = gamma / torch.sqrt(rv + 1e-5)
-    assert torch.equal(wf.float().cpu(), R.bf16_round(w * scale.view(-1, 1, 1, 1)))
+    # the fold multiplies in fp32 on both sides; the device's 1/sqrt differs from the host's in the last bit for a few channels,
+    # which moves a product across a bf16 rounding boundary once in ~1e5 elements: one ulp at most, almost all exact
+    wf_ref = R.bf16_round(w * scale.view(-1, 1, 1, 1))
+    assert R.max_bf16_ulp(wf.float().cpu(), wf_ref) <= 1.0
+    assert float((wf.float().cpu() != wf_ref).float().mean()) <= 1e-4
     assert torch.allclose(shift.cpu(), beta - rm * scale, rtol=1e-6, atol=1e-7)
     xd, rd = to_dev_bf16(x), to_dev_bf16(res)
     for use_res, relu in ((False, True), (True, True), (True, False)):
