@@ -37,7 +37,11 @@ namespace {
 // read of dout and y) disappears for that BatchNorm; this kernel reads y once instead.
 // EPI (round 4): the inference epilogue of evaluate()'s BatchNorm-folded forward (engine.py:145-225): + bias[n] in fp32, + addend
 // (the ADD patch), ReLU, ONE rounding -- the arithmetic of conv_igemm's fused epilogue, which these launches used to run on.
-template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false, bool BNR = false, bool EPI = false>
+// ABL (round 4, measurement only, ICAMD_PW_ABLATE_WGRAD=1 on the K = 256 / N = 64 data gradient): the cost model of a fused
+// data-gradient + weight-gradient kernel before building it -- per tile one more 8 KB LDS-DMA (the x tile,
+// read from real memory: the dx buffer), 32 transposed LDS reads and 32 more MFMAs per wave into 16 more accumulators (a
+// [256][64] fp32 filter gradient over four waves); results are garbage and unused.
+template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false, bool BNR = false, bool EPI = false, bool ABL = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
@@ -53,8 +57,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int P_WAVE = ADD ? MF * 16 * EROW : 0;   // ADD: this wave's [MF*16 rows][CW] addend patch (LDS-DMA target)
   constexpr int Y_WAVE = BNR ? MF * 16 * EROW : 0;   // BNR: the same shape for the BatchNorm input y
   static_assert(!BNR || (ADD && NF == 4 && WN == 4 && !EXT), "bnred: 256-channel workgroups with an addend");
-  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE <= 80 * 1024, "two workgroups per CU");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE];
+  constexpr int X_BYTES = 0;
+  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE + X_BYTES];
+  f32x4 gacc[ABL ? 8 : 1];   // (8, not the 16 a [256][64] gradient needs: with 16 the kernel spills and every reload drains the LDS-DMA queue)
+  if constexpr (ABL) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) gacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,6 +226,31 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
       });
     });
 
+    if constexpr (ABL) {
+      // (second form of the ablation: no x-tile DMA -- its 103 MB are priced separately -- and no mid-tile wait: the first form
+      // drained the NEXT tile's staging loads with a vmcnt(0) and ran 321 us; both operands are read from the dy tile)
+      unsigned char* const sX = smem + BUF * A_BYTES + 256;
+      typedef bf16x4 __attribute__((address_space(3))) * lp4;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const unsigned char* pb = sX + (kk * 32 + (lane & 15)) * ROWB + f * 32 + (lane >> 4) * 8;
+          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)pb), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(pb + 16 * ROWB));
+          bfr[f] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+#pragma unroll
+        for (int fa = 0; fa < 4; ++fa) {
+          const unsigned char* pa = smem + BUF * A_BYTES + (kk * 32 + (lane & 15)) * ROWB + (wave * 4 + fa) * 32 + (lane >> 4) * 8;
+          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)pa), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(pa + 16 * ROWB));
+          const bf16x8 af = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+          for (int fb = 0; fb < 4; ++fb)
+            gacc[(fa & 1) * 4 + fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[fb], gacc[(fa & 1) * 4 + fb], 0, 0, 0);
+        }
+      }
+    }
     // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
     if constexpr (ADD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's addend patch (and bit words) landed
     static_for<0, (MF + 1) / 2>([&](auto hc) {
@@ -324,6 +359,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     tile(std::integral_constant<int, 1>{}, m0 + TM);
   }
 
+  if constexpr (ABL) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) asm volatile("" ::"v"(gacc[f]));
+  }
   if (want_stats) {
     // one partial row per workgroup (row `split` of the [ceil(M/128)] table); rows no workgroup owns are zero
     __syncthreads();
@@ -390,8 +429,17 @@ int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
     // (K = 256 with 32-channel waves: activation buffers + addend patches exceed the 80 KB of two workgroups per CU)
     if constexpr (KS == 8 && NF == 2 && WN == 4) return ICAMD_ERR_UNSUPPORTED;
     else hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-  } else
+  } else {
+    if constexpr (KS == 8 && NF == 2 && MF == 2 && WN == 2) {
+      static const int abl = [] { const char* e = getenv("ICAMD_PW_ABLATE_WGRAD"); return e ? atoi(e) : 0; }();
+      if (abl && p.stats == nullptr) {
+        hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0,
+                           stream, p);
+        return icamd_launch_status();
+      }
+    }
     hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  }
   return icamd_launch_status();
 }
 
