@@ -368,16 +368,24 @@ class ConvNeXt(PicklableModel):
             rates = [blk["rate"] for st in self.stages for blk in st["blocks"]]
             if any(r > 0.0 for r in rates):
                 kp = 1.0 - torch.tensor(rates, dtype=torch.float32).view(-1, 1)
-                host = ws.get("keep_host")
-                if host is None or host.shape != (len(rates), N):
-                    host = ws["keep_host"] = torch.empty(len(rates), N, dtype=torch.float32).pin_memory()
+                # a ring of 4 pinned staging rows: the upload of step i is enqueued behind step i's stem kernels, so waiting for it
+                # before the NEXT draw (one buffer, rounds 2-3) tied the host to within one step of the device (12 ms of the host's
+                # step spent in Event.synchronize, round-4 profile); with four rows the wait is for the upload issued 4 steps ago
+                ring = ws.get("keep_host")
+                if ring is None or ring.shape[1:] != (len(rates), N):
+                    ring = ws["keep_host"] = torch.empty(4, len(rates), N, dtype=torch.float32).pin_memory()
                     ws["keep_dev"] = torch.empty(len(rates), N, dtype=torch.float32, device=self.device)
-                if ws.get("keep_copied") is not None:
-                    ws["keep_copied"].synchronize()   # the previous step's upload (issued a whole step ago) has left `host`
+                    ws["keep_copied"] = [None] * 4
+                    ws["keep_slot"] = 0
+                slot = ws["keep_slot"]
+                ws["keep_slot"] = (slot + 1) % 4
+                host = ring[slot]
+                if ws["keep_copied"][slot] is not None:
+                    ws["keep_copied"][slot].synchronize()   # the upload that last used this row has left it
                 torch.div((torch.rand(len(rates), N) < kp).float(), kp, out=host)
                 ws["keep_dev"].copy_(host, non_blocking=True)
-                ws["keep_copied"] = torch.cuda.Event()
-                ws["keep_copied"].record()
+                ws["keep_copied"][slot] = torch.cuda.Event()
+                ws["keep_copied"][slot].record()
                 drop_rows = ws["keep_dev"]
         for si, (st, sw) in enumerate(zip(self.stages, ws["stages"])):
             dim = st["dim"]

@@ -70,7 +70,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
   const int fr = lane & 15, fq = lane >> 4;
-  const int tile_n = blockIdx.x % p.ntiles_n, split = blockIdx.x / p.ntiles_n;
+  // Workgroup -> (row range `split`, channel tile `tile_n`).  Round 4: XCD-aware.  The ntiles_n channel tiles of one row range
+  // stage the SAME activation tiles; numbered consecutively (rounds 2-3) they land on ntiles_n different XCDs (dispatch is
+  // round-robin: workgroup w runs on XCD w % 8) and every one fetches the tile beyond its own L2 -- PMC on ConvNeXt-T's 96 -> 384
+  // layers (3 tiles): 638 MB fetched per launch for 359 MB of operands, L2 hit rate 36 %.  Placed 8 apart they share an XCD, run
+  // side by side (all workgroups of the grid are resident) and share the tile in its L2.
+  int tile_n, split;
+  {
+    const int ntn = p.ntiles_n, S = (int)gridDim.x / ntn, G = p.xcd_groups ? (S / 8) * 8 : 0;
+    const int w = (int)blockIdx.x;
+    if (w < G * ntn) {
+      const int r = w % (8 * ntn);
+      tile_n = r / 8;
+      split = (w / (8 * ntn)) * 8 + (r & 7);
+    } else {
+      const int r = w - G * ntn;
+      tile_n = r % ntn;
+      split = G + r / ntn;
+    }
+  }
   const int n0 = (tile_n * WN + wn) * CW;       // this wave's first channel
   const int m_begin = split * p.rows_per_split;
   const int m_end = (p.M < m_begin + p.rows_per_split) ? p.M : m_begin + p.rows_per_split;
@@ -396,6 +414,10 @@ int mode() {
   static const int m = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e ? atoi(e) : 1; }();
   return m;
 }
+int xcd_order() {   // ICAMD_PW_XCD=0: the consecutive numbering of rounds 2-3 (A/B runs)
+  static const int m = [] { const char* e = getenv("ICAMD_PW_XCD"); return e ? atoi(e) : 1; }();
+  return m;
+}
 
 struct Config { int ks, nf, mf, wn; };
 
@@ -475,6 +497,7 @@ int icamd_pw_resident_bnred_launch(PwResidentParams& p, hipStream_t stream) {
     p.divHW = make_fastdiv((unsigned)(p.sub2_h * p.sub2_w));
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
+  p.xcd_groups = xcd_order();
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (p.K == 64) hipLaunchKernelGGL((conv1x1_resident_kernel<2, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
   else if (p.K == 128) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
@@ -503,6 +526,7 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   rows = (rows + tm - 1) / tm * tm;
   p.rows_per_split = rows;
   S = (p.M + rows - 1) / rows;
+  p.xcd_groups = xcd_order();
   hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
   return icamd_launch_status();
 }
@@ -549,6 +573,7 @@ int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
   const int grid = S * p.ntiles_n;
+  p.xcd_groups = xcd_order();
   if (c.ks == 2 && c.wn == 4) return launch<2, 4, 4, 4>(p, grid, stream);
   if (c.ks == 2) return launch<2, 4, 1, 1>(p, grid, stream);
   if (c.ks == 4) return launch<4, 4, 4, 4>(p, grid, stream);

@@ -91,6 +91,7 @@ struct PwResidentParams {
   int sub2_h, sub2_w;    // > 0: addend is [.][ceil(h/2)][ceil(w/2)][N], added at even (h, w)
   FastDiv divHW, divW;   // filled by the launcher
   int rows_per_split, ntiles_n;   // filled by the launcher
+  int xcd_groups;                 // filled by the launcher: XCD-aware workgroup -> (row range, channel tile) order
   // "ext" launches (ConvNeXt's dim-96 Linear layers: K = 96 runs as four 32-wide k-steps, the last one against zero filter
   // columns): A rows are lda elements apart and only Ktrue of the K = 128 staged columns are real
   // "bnred" launches (residual data gradient whose output is the output gradient of the PREVIOUS block's last BatchNorm):

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round evidence, part A / B (one gpurun call each: a call is capped at 20 minutes).  Run on the GPU box from the repo root:
-#   ROUND=r03 bash tools/profile_round.sh A     bench lines of the three model families + rocprofv3 kernel stats
-#   ROUND=r03 bash tools/profile_round.sh C     the three bench lines again, once part B's summaries are in profiles/
-#   ROUND=r03 bash tools/profile_round.sh B     PMC passes (HBM traffic per arch, MFMA busy), per-layer / GEMM / depthwise tables
-# then, here: python tools/summarize_profiles.py gpurun_out/prof_r03 r03
+#   ROUND=r04 bash tools/profile_round.sh A     bench lines of the three model families + rocprofv3 kernel stats
+#   ROUND=r04 bash tools/profile_round.sh C     the three bench lines again, once part B's summaries are in profiles/
+#   ROUND=r04 bash tools/profile_round.sh B     PMC passes (HBM traffic per arch, MFMA busy), per-layer / GEMM / depthwise tables
+# then, here: python tools/summarize_profiles.py gpurun_out/prof_r04 r04
 PART=${1:-A}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_${ROUND:-r03}
+O=$R/gpurun_out/prof_${ROUND:-r04}
 mkdir -p $O
 VIT="--arch vit_base_patch16_224"
 CNX="--arch convnext_tiny --mixup"
@@ -16,11 +16,13 @@ if [ "$PART" = "C" ]; then
   python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_r50.json 2> $O/bench_r50.err
   python3 $R/bench.py $VIT --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_vit.json 2> $O/bench_vit.err
   python3 $R/bench.py $CNX --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cnx.json 2> $O/bench_cnx.err
+  python3 $R/bench.py --mode eval --steps 20 --warmup 5 > $O/bench_eval.json 2> $O/bench_eval.err
 elif [ "$PART" = "A" ]; then
   echo "== bench lines"; date
   python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_r50.json 2> $O/bench_r50.err
   python3 $R/bench.py $VIT --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_vit.json 2> $O/bench_vit.err
   python3 $R/bench.py $CNX --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cnx.json 2> $O/bench_cnx.err
+  python3 $R/bench.py --mode eval --steps 20 --warmup 5 > $O/bench_eval.json 2> $O/bench_eval.err
   echo "== kernel stats"; date
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_r50 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_r50.log 2>&1
   export ICAMD_WGRAD_STREAM=0
@@ -28,12 +30,13 @@ elif [ "$PART" = "A" ]; then
   unset ICAMD_WGRAD_STREAM
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vit -- python3 $R/bench.py $VIT --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_vit.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cnx -- python3 $R/bench.py $CNX --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_cnx.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eval -- python3 $R/bench.py --mode eval --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_eval.log 2>&1
   date
 else
   echo "== pmc"; date
   export ICAMD_WGRAD_STREAM=0
-  for a in r50 vit cnx; do
-    case $a in r50) ARGS="";; vit) ARGS="$VIT";; cnx) ARGS="$CNX";; esac
+  for a in r50 vit cnx eval; do
+    case $a in r50) ARGS="";; vit) ARGS="$VIT";; cnx) ARGS="$CNX";; eval) ARGS="--mode eval";; esac
     rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$a -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$a.log 2>&1
     rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$a -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$a.log 2>&1
     date
@@ -50,9 +53,10 @@ else
   python3 tools/bench_dwconv.py > $O/dwconv.txt 2>&1
   python3 tools/bench_cnx_layers.py 256 10 2>&1 | grep -v amdgpu.ids > $O/cnx_layers.txt
   python3 tools/bench_attn.py 256 20 2>&1 | grep -v amdgpu.ids > $O/attention.txt
-  # 7 steps per PMC run: 1 warm-up + 3 timed + 3 in the per-class timing pass
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_r50 -name "*.db" | head -1) $(find $O/pmc_write_r50 -name "*.db" | head -1) 7 $O/pmc_traffic_r50.json resnet50 256
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_vit -name "*.db" | head -1) $(find $O/pmc_write_vit -name "*.db" | head -1) 7 $O/pmc_traffic_vit.json vit_base_patch16_224 256
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_cnx -name "*.db" | head -1) $(find $O/pmc_write_cnx -name "*.db" | head -1) 7 $O/pmc_traffic_cnx.json convnext_tiny 256
+  # 10 steps per PMC run: 1 warm-up + 3 timed + the 3-step host-enqueue burst + 3 in the per-class timing pass
+  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_r50 -name "*.db" | head -1) $(find $O/pmc_write_r50 -name "*.db" | head -1) 10 $O/pmc_traffic_r50.json resnet50 256
+  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_vit -name "*.db" | head -1) $(find $O/pmc_write_vit -name "*.db" | head -1) 10 $O/pmc_traffic_vit.json vit_base_patch16_224 256
+  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_cnx -name "*.db" | head -1) $(find $O/pmc_write_cnx -name "*.db" | head -1) 10 $O/pmc_traffic_cnx.json convnext_tiny 256
+  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_eval -name "*.db" | head -1) $(find $O/pmc_write_eval -name "*.db" | head -1) 10 $O/pmc_traffic_eval.json resnet50 384 eval
   date
 fi

@@ -1,5 +1,5 @@
 """Copy the outputs of tools/profile_round.sh (gpurun_out/prof_<round>/, parts A and B) into profiles/ and build the PMC summaries.
-usage: python tools/summarize_profiles.py gpurun_out/prof_r03 r03"""
+usage: python tools/summarize_profiles.py gpurun_out/prof_r04 r04"""
 import collections
 import csv
 import glob
@@ -44,12 +44,14 @@ def copy(src, dst):
 
 
 for src, dst in [("bench_r50.json", "bench_n1.json"), ("bench_vit.json", "bench_vit.json"), ("bench_cnx.json", "bench_convnext.json"),
+                 ("bench_eval.json", "bench_eval.json"), ("pmc_traffic_eval.json", "pmc_traffic_eval.json"),
                  ("layers.txt", "per_layer_table.txt"), ("gemm_shapes.txt", "gemm_shapes.txt"), ("dwconv.txt", "dwconv.txt"), ("cnx_layers.txt", "convnext_linear_layers.txt"), ("attention.txt", "attention.txt"),
                  ("pmc_traffic_r50.json", "pmc_traffic.json"), ("pmc_traffic_vit.json", "pmc_traffic_vit.json"),
                  ("pmc_traffic_cnx.json", "pmc_traffic_convnext.json")]:
     copy(src, dst)
 for d, dst in [("stats_r50", "bench_n1_kernel_stats.csv"), ("stats_r50_1s", "bench_n1_kernel_stats_single_stream.csv"),
-               ("stats_vit", "vit_b16_kernel_stats.csv"), ("stats_cnx", "convnext_t_mixup_ema_kernel_stats.csv")]:
+               ("stats_vit", "vit_b16_kernel_stats.csv"), ("stats_cnx", "convnext_t_mixup_ema_kernel_stats.csv"),
+               ("stats_eval", "eval_kernel_stats.csv")]:
     try:
         shutil.copy(one(f"{d}/**/*kernel_stats.csv"), f"{P}/{TAG}_{dst}")
         print("copied", dst)
@@ -74,7 +76,7 @@ for d, dst, what in [("pmc_mfma", "pmc_mfma_busy.json", "bench.py"), ("pmc_mfma_
                          "(single stream); busy fraction = MFMA busy cycles / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)",
                "kernels": out}, open(f"{P}/{TAG}_{dst}", "w"), indent=1)
     print(dst, {k: v["mfma_busy_frac"] for k, v in list(out.items())[:10]})
-for f in ("bench_n1.json", "bench_vit.json", "bench_convnext.json"):
+for f in ("bench_n1.json", "bench_vit.json", "bench_convnext.json", "bench_eval.json"):
     try:
         d = json.loads(open(f"{P}/{TAG}_{f}").readline())
         print(f, d["value"], d["ms_per_step"], d["roofline"])
