@@ -40,7 +40,9 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 }
 
 // y = (x - mean) * rstd * gamma + beta (two-pass variance in registers, as torch.nn.functional.layer_norm)
-template <int LPR>
+// NV (round 4): 16 B vectors per lane, 1 when the row fits LPR vectors (C <= 8 * LPR: every ConvNeXt-T LayerNorm but the 768-wide
+// ones) -- half the registers of the two-vector form, twice the waves in flight for kernels that live on loads in flight.
+template <int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -49,10 +51,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int nvec = C >> 3;
-  const bool has[2] = {sub < nvec, sub + LPR < nvec};
-  float g[2][8], bt[2][8];
+  const bool has[2] = {sub < nvec, NV > 1 && sub + LPR < nvec};
+  float g[NV][8], bt[NV][8];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NV; ++it) {
     const int c = (has[it] ? sub + it * LPR : 0) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { g[it][e] = gamma[c + e]; bt[it][e] = beta[c + e]; }
@@ -63,10 +65,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     const long long row = rbase + grp;
     const bool live = row < rows;
     const bf16_t* xr = x + (live ? row : 0) * C;
-    float v[2][8];
+    float v[NV][8];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NV; ++it) {
       u32x4 raw = {0u, 0u, 0u, 0u};
       if (has[it] && live) raw = *(const u32x4*)(xr + (sub + it * LPR) * 8);
       unpack8(raw, v[it]);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     const float mean = group_sum<LPR>(s) * invC;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NV; ++it)
       if (has[it]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = v[it][e] - mean; q += d * d; }
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     if (sub == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     bf16_t* yr = y + row * C;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NV; ++it)
       if (has[it]) {
         float o[8];
 #pragma unroll
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 
 // dx = rstd * (dy*gamma - mean_C(dy*gamma) - xhat * mean_C(dy*gamma*xhat)) (+ addend); per-workgroup partial column
 // sums of dy (-> dbeta) and dy*xhat (-> dgamma) in part[blk][2][C].  Each wave walks `rows_per_wave` rows, 64/LPR at a time.
-template <int LPR>
-__global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+template <int LPR, int NV>
+__global__ __launch_bounds__(256, NV == 1 ? 4 : 3) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const bf16_t* __restrict__ addend,
                                                             bf16_t* __restrict__ dx, float* __restrict__ part, long long rows,
@@ -109,13 +111,13 @@ __global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int nvec = C >> 3;
-  const bool has[2] = {sub < nvec, sub + LPR < nvec};
+  const bool has[2] = {sub < nvec, NV > 1 && sub + LPR < nvec};
   // Column sums (d beta, d gamma) and gamma as PACKED pairs in the order the 16 B vectors hold them (element 2e in .x, 2e + 1
   // in .y): every pair the packed-fp32 instructions see is then a natural VGPR pair and no op_sel swizzle is needed.  That is
   // a correctness matter on this part, not a style one -- see the note at the accumulation below.
-  f32x2 g2[2][4], sb[2][4], sg[2][4];
+  f32x2 g2[NV][4], sb[NV][4], sg[NV][4];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NV; ++it) {
     const int c = (has[it] ? sub + it * LPR : 0) * 8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __r
   // Software-pipelined over rows: the raw vectors (dy, x, addend) and statistics of the NEXT row group are requested
   // before the current one is reduced, so every wave keeps two rows of loads in flight (the kernel is latency-bound at
   // the 12 waves per CU its registers allow).
-  u32x4 nd[2], nx[2], na[2];
+  u32x4 nd[NV], nx[NV], na[NV];
   float nmu = 0.f, nrs = 0.f;
   auto fetch = [&](long long rbase) {
     const long long row = rbase + grp;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __r
     nmu = live ? mean[row] : 0.f;
     nrs = live ? rstd[row] : 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NV; ++it) {
       nd[it] = u32x4{0u, 0u, 0u, 0u}; nx[it] = nd[it]; na[it] = nd[it];
       if (has[it] && live) {
         nd[it] = *(const u32x4*)(dy + ro + (sub + it * LPR) * 8);
@@ -154,14 +156,14 @@ __global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __r
     const bool live = row < r1;
     const long long ro = (live ? row : 0) * C;
     const float mu = nmu, rs = nrs;
-    u32x4 rd[2], rx[2], ra[2];
+    u32x4 rd[NV], rx[NV], ra[NV];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { rd[it] = nd[it]; rx[it] = nx[it]; ra[it] = na[it]; }
+    for (int it = 0; it < NV; ++it) { rd[it] = nd[it]; rx[it] = nx[it]; ra[it] = na[it]; }
     if (rbase + RPW < r1) fetch(rbase + RPW);
-    f32x2 dyg[2][4], xh[2][4];
+    f32x2 dyg[NV][4], xh[NV][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const bool on = has[it] && live;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __r
     const float c1 = group_sum<LPR>(s1) * invC, c2 = group_sum<LPR>(s2) * invC;
     if (!live) continue;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NV; ++it)
       if (has[it]) {
         u32x4 ov;
 #pragma unroll
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 3) void layernorm_bwd_kernel(const bf16_t* __r
   }
   // fold: lane groups of the wave (fixed xor order), then the 4 waves in wave order; one partial row per workgroup
 #pragma unroll
-  for (int it = 0; it < 2; ++it)
+  for (int it = 0; it < NV; ++it)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float b = cross_group_sum<LPR>(sb[it][e >> 1][e & 1]), gg = cross_group_sum<LPR>(sg[it][e >> 1][e & 1]);
@@ -351,9 +353,12 @@ int icamd_layernorm_fwd_launch(const bf16_t* x, const float* gamma, const float*
   if (blocks > 2048) blocks = 2048;   // grid-stride beyond: 8 workgroups per CU keep enough loads in flight
   if (blocks < 1) blocks = 1;
   const dim3 grid((unsigned)blocks), block(256);
-  if (lpr == 16) hipLaunchKernelGGL(layernorm_fwd_kernel<16>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
-  else if (lpr == 32) hipLaunchKernelGGL(layernorm_fwd_kernel<32>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
-  else hipLaunchKernelGGL(layernorm_fwd_kernel<64>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  const bool one = C <= 8 * lpr;   // one 16 B vector per lane
+#define ICAMD_LN_FWD(L, V) hipLaunchKernelGGL((layernorm_fwd_kernel<L, V>), grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps)
+  if (lpr == 16) { if (one) ICAMD_LN_FWD(16, 1); else ICAMD_LN_FWD(16, 2); }
+  else if (lpr == 32) { if (one) ICAMD_LN_FWD(32, 1); else ICAMD_LN_FWD(32, 2); }
+  else { if (one) ICAMD_LN_FWD(64, 1); else ICAMD_LN_FWD(64, 2); }
+#undef ICAMD_LN_FWD
   return icamd_launch_status();
 }
 
@@ -370,12 +375,13 @@ int icamd_layernorm_bwd_launch(const bf16_t* dy, const bf16_t* x, const float* m
   const int rpw = (int)((rows + (long long)nblk * 4 - 1) / ((long long)nblk * 4));
   const int lpr = ln_lanes_per_row(C);
   const dim3 grid((unsigned)nblk), block(256);
-  if (lpr == 16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<16>, grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw);
-  else if (lpr == 32)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<32>, grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<64>, grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw);
+  const bool one = C <= 8 * lpr;
+#define ICAMD_LN_BWD(L, V) \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<L, V>), grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw)
+  if (lpr == 16) { if (one) ICAMD_LN_BWD(16, 1); else ICAMD_LN_BWD(16, 2); }
+  else if (lpr == 32) { if (one) ICAMD_LN_BWD(32, 1); else ICAMD_LN_BWD(32, 2); }
+  else { if (one) ICAMD_LN_BWD(64, 1); else ICAMD_LN_BWD(64, 2); }
+#undef ICAMD_LN_BWD
   return icamd_launch_status();
 }
 

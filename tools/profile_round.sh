@@ -24,27 +24,41 @@ elif [ "$PART" = "A" ]; then
   python3 $R/bench.py $CNX --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cnx.json 2> $O/bench_cnx.err
   python3 $R/bench.py --mode eval --steps 20 --warmup 5 > $O/bench_eval.json 2> $O/bench_eval.err
   echo "== kernel stats"; date
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_r50 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_r50.log 2>&1
+  RAWA=/tmp/icamd_prof_raw_a; rm -rf $RAWA; mkdir -p $RAWA
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAWA/stats_r50 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_r50.log 2>&1
   export ICAMD_WGRAD_STREAM=0
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_r50_1s -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_r50_1s.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAWA/stats_r50_1s -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_r50_1s.log 2>&1
   unset ICAMD_WGRAD_STREAM
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vit -- python3 $R/bench.py $VIT --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_vit.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cnx -- python3 $R/bench.py $CNX --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_cnx.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_eval -- python3 $R/bench.py --mode eval --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_eval.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAWA/stats_vit -- python3 $R/bench.py $VIT --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_vit.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAWA/stats_cnx -- python3 $R/bench.py $CNX --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_cnx.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAWA/stats_eval -- python3 $R/bench.py --mode eval --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_eval.log 2>&1
+  for d in stats_r50 stats_r50_1s stats_vit stats_cnx stats_eval; do
+    mkdir -p $O/$d
+    cp $(find $RAWA/$d -name "*kernel_stats.csv" | head -1) $O/$d/kernel_stats.csv
+  done
   date
 else
+  # raw rocprofv3 output (databases, per-dispatch CSVs: > 64 MiB in all) stays in /tmp on the GPU box; only the summaries and the
+  # counter CSVs the MFMA-busy tables are built from go to gpurun_out/ (gpurun merges at most 64 MiB back)
+  RAW=/tmp/icamd_prof_raw
+  rm -rf $RAW; mkdir -p $RAW
   echo "== pmc"; date
   export ICAMD_WGRAD_STREAM=0
   for a in r50 vit cnx eval; do
     case $a in r50) ARGS="";; vit) ARGS="$VIT";; cnx) ARGS="$CNX";; eval) ARGS="--mode eval";; esac
-    rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$a -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$a.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_$a -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$a.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE -d $RAW/pmc_fetch_$a -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$a.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE -d $RAW/pmc_write_$a -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$a.log 2>&1
     date
   done
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_vit -- python3 $R/bench.py $VIT --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_vit.log 2>&1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_cnx -- python3 $R/bench.py $CNX --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_cnx.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $RAW/pmc_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $RAW/pmc_mfma_vit -- python3 $R/bench.py $VIT --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_vit.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $RAW/pmc_mfma_cnx -- python3 $R/bench.py $CNX --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_cnx.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $RAW/pmc_mfma_eval -- python3 $R/bench.py --mode eval --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_mfma_eval.log 2>&1
   unset ICAMD_WGRAD_STREAM
+  for d in pmc_mfma pmc_mfma_vit pmc_mfma_cnx pmc_mfma_eval; do
+    mkdir -p $O/$d
+    cp $(find $RAW/$d -name "*counter_collection.csv" | head -1) $O/$d/counter_collection.csv
+  done
   echo "== tables"; date
   cd $R
   python3 tools/bench_layers.py 256 10 > $O/layers.txt 2>&1
@@ -54,9 +68,10 @@ else
   python3 tools/bench_cnx_layers.py 256 10 2>&1 | grep -v amdgpu.ids > $O/cnx_layers.txt
   python3 tools/bench_attn.py 256 20 2>&1 | grep -v amdgpu.ids > $O/attention.txt
   # 10 steps per PMC run: 1 warm-up + 3 timed + the 3-step host-enqueue burst + 3 in the per-class timing pass
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_r50 -name "*.db" | head -1) $(find $O/pmc_write_r50 -name "*.db" | head -1) 10 $O/pmc_traffic_r50.json resnet50 256
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_vit -name "*.db" | head -1) $(find $O/pmc_write_vit -name "*.db" | head -1) 10 $O/pmc_traffic_vit.json vit_base_patch16_224 256
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_cnx -name "*.db" | head -1) $(find $O/pmc_write_cnx -name "*.db" | head -1) 10 $O/pmc_traffic_cnx.json convnext_tiny 256
-  python3 tools/pmc_traffic.py $(find $O/pmc_fetch_eval -name "*.db" | head -1) $(find $O/pmc_write_eval -name "*.db" | head -1) 10 $O/pmc_traffic_eval.json resnet50 384 eval
+  python3 tools/pmc_traffic.py $(find $RAW/pmc_fetch_r50 -name "*.db" | head -1) $(find $RAW/pmc_write_r50 -name "*.db" | head -1) 10 $O/pmc_traffic_r50.json resnet50 256
+  python3 tools/pmc_traffic.py $(find $RAW/pmc_fetch_vit -name "*.db" | head -1) $(find $RAW/pmc_write_vit -name "*.db" | head -1) 10 $O/pmc_traffic_vit.json vit_base_patch16_224 256
+  python3 tools/pmc_traffic.py $(find $RAW/pmc_fetch_cnx -name "*.db" | head -1) $(find $RAW/pmc_write_cnx -name "*.db" | head -1) 10 $O/pmc_traffic_cnx.json convnext_tiny 256
+  python3 tools/pmc_traffic.py $(find $RAW/pmc_fetch_eval -name "*.db" | head -1) $(find $RAW/pmc_write_eval -name "*.db" | head -1) 10 $O/pmc_traffic_eval.json resnet50 384 eval
+  du -sh $O
   date
 fi

@@ -59,7 +59,8 @@ for d, dst in [("stats_r50", "bench_n1_kernel_stats.csv"), ("stats_r50_1s", "ben
         print("MISSING", d)
 
 for d, dst, what in [("pmc_mfma", "pmc_mfma_busy.json", "bench.py"), ("pmc_mfma_vit", "pmc_mfma_busy_vit.json", "bench.py --arch vit_base_patch16_224"),
-                     ("pmc_mfma_cnx", "pmc_mfma_busy_convnext.json", "bench.py --arch convnext_tiny --mixup")]:
+                     ("pmc_mfma_cnx", "pmc_mfma_busy_convnext.json", "bench.py --arch convnext_tiny --mixup"),
+                     ("pmc_mfma_eval", "pmc_mfma_busy_eval.json", "bench.py --mode eval")]:
     try:
         acc, n = load(d)
     except IndexError:
