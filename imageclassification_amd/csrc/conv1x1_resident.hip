@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int IPW = NINST / 4;                // per wave
   static_assert(NINST % 4 == 0 && (NF == 2 || NF == 4) && KS >= 2 && KS <= 16, "configuration");
   constexpr int P_WAVE = ADD ? MF * 16 * EROW : 0;   // ADD: this wave's [MF*16 rows][CW] addend patch (LDS-DMA target)
-  constexpr int Y_WAVE = BNR ? MF * 16 * EROW : 0;   // BNR: the same shape for the BatchNorm input y
+  // BNR: the same shape for the BatchNorm input y.  EXT (round 4): the same patch carries the pre-GELU activations z of the
+  // "data gradient x gelu'(z)" form: read per row group from global memory inside the store pass they cost a full load latency
+  // four times per tile (455 us for 1.39 GB at ConvNeXt-T's stage 0); as a patch they land under the MFMAs.
+  constexpr int Y_WAVE = (BNR || EXT) ? MF * 16 * EROW : 0;
   static_assert(!BNR || (ADD && NF == 4 && WN == 4 && !EXT), "bnred: 256-channel workgroups with an addend");
   constexpr int X_BYTES = 0;
   static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
@@ -229,6 +232,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
         }
       }
     }
+    if constexpr (EXT) {
+      if (p.gelu_z != nullptr) {
+        constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;
+#pragma unroll
+        for (int q = 0; q < Y_WAVE / 1024; ++q) {
+          const int row = q * RPIA + lane / LPRA, pos = lane % LPRA;
+          const int chunk = pos ^ (row & (LPRA - 1));
+          const int m = mw + row;
+          const bf16_t* src = m < p.M ? p.gelu_z + ((long long)m * p.N + n0 + chunk * 8) : zero;
+          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sY + q * 1024), 16, 0, 0);
+        }
+      }
+    }
     static_for<0, KS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
       bf16x8 xf[MF];
@@ -271,6 +287,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     }
     // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
     if constexpr (ADD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's addend patch (and bit words) landed
+    if constexpr (EXT) {
+      if (p.gelu_z != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's z patch landed
+    }
     static_for<0, (MF + 1) / 2>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
 #pragma unroll
@@ -329,7 +348,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           if (m < m_end) {
             if constexpr (EXT) {
               const long long off = (long long)m * p.N + n0 + c * 8;
-              if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
+              if (p.gelu_z != nullptr) {
+                const int pr = i * 16 + rr;                  // row of the wave's z patch; chunk c sits at c ^ (row & (LPR - 1))
+                o = gelu_bwd8(o, *(const u32x4*)(sY + pr * EROW + (((c ^ pr) & (LPR - 1)) << 4)));
+              }
               if (p.gelu_inplace) o = gelu8(o);
               if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
             }
@@ -361,16 +383,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     });
   };
 
+  // The tile's staging loads are older than the previous tile's row stores in the in-order vmcnt queue: leave exactly those
+  // stores in flight.  A forward that writes z AND gelu(z) (EXT, round 4) issues 2 * STORES of them -- with the single count it
+  // waited for half of its own stores to reach memory before every tile.
+  const bool two_outputs = EXT && p.gelu_out != nullptr;
+  auto wait_tile_loads = [&]() {
+    if (two_outputs) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * STORES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
+  };
   for (; m0 < m_end; m0 += 2 * TM) {
     // this tile has landed for every wave and every wave is done with the other buffer; behind the tile's loads in the
     // queue: the previous tile's STORES row stores (full tiles always issue all of them; a ragged tile is a range's last)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
+    wait_tile_loads();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (m0 + TM < m_end) stage(m0 + TM, 1);
     tile(std::integral_constant<int, 0>{}, m0);
     if (m0 + TM >= m_end) break;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
+    wait_tile_loads();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (m0 + 2 * TM < m_end) stage(m0 + 2 * TM, 0);

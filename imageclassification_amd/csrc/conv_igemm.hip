@@ -372,6 +372,17 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
   }
   __syncthreads();
 
+  // Round 4: the pre-GELU activations z of the "x gelu'(z)" form for ALL passes up front.  Read inside the pass loop (rounds 2-3)
+  // every load sat behind the previous pass's store -- the compiler may not hoist a load above a store to memory that could
+  // alias -- and each of the 8 passes of a tile paid a full load latency (ConvNeXt-T's fc2 data gradient: 1.55-2x its twin
+  // without GELU at every stage).  The accumulators are dead here (the tile is in LDS), so the registers are free.
+  u32x4 zv[EPI < 2 ? NPASS : 1];
+  if constexpr (EPI < 2) {
+    if (p.gelu_z != nullptr) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) zv[ps] = *(const u32x4*)(p.gelu_z + (roff[ps] >= 0 ? roff[ps] : 0));
+    }
+  }
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256, (ICAMD_IGEMM_STAGES == 1 ? (EPI == 1 ? 3 : 4) 
         }
       } else {
         if constexpr (EPI < 2) {
-          if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + roff[ps]));
+          if (p.gelu_z != nullptr) o = gelu_bwd8(o, zv[ps]);
           if (p.gelu_inplace) o = gelu8(o);
         }
         *(u32x4*)(p.out + roff[ps]) = o;

@@ -111,14 +111,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtParams& p, unsigned ch
   f32x2 s1[4], s2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
-#pragma unroll 4
-  for (int ps = 0; ps < TM / RPP; ++ps) {
+  // (round 4) the x gelu'(z) form reads z four passes ahead of the stores: inside the loop every load sat behind the previous
+  // pass's store (possible alias) and each pass paid a full load latency
+  constexpr int NPS = TM / RPP, ZG = 4;
+  u32x4 zv[ZG];
+  const bool has_z = p.gelu_z != nullptr;
+#pragma unroll 1
+  for (int pg = 0; pg < NPS; pg += ZG) {
+    if (has_z) {
+#pragma unroll
+      for (int u = 0; u < ZG; ++u) {
+        const int m = m0 + (pg + u) * RPP + rg;
+        zv[u] = (m < p.M && co < p.N) ? *(const u32x4*)(p.gelu_z + (long long)m * p.N + co) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+  for (int u = 0; u < ZG; ++u) {
+    const int ps = pg + u;
     const int ml = ps * RPP + rg;
     const int m = m0 + ml;
     u32x4 o = *(const u32x4*)(smem + ml * ROWB + (((cp ^ ml) & (CPR - 1)) << 4));
     if (m < p.M && co < p.N) {
       const long long off = (long long)m * p.N + co;
-      if (p.gelu_z != nullptr) o = gelu_bwd8(o, *(const u32x4*)(p.gelu_z + off));
+      if (has_z) o = gelu_bwd8(o, zv[u]);
       if (p.gelu_inplace) o = gelu8(o);
       *(u32x4*)(p.out + off) = o;
       if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
@@ -131,6 +146,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtParams& p, unsigned ch
         }
       }
     }
+  }
   }
   if (want_stats) {
     // BatchNorm statistics of the rounded outputs: one partial row per 256-row tile (row tile_m of the [ceil(M/128)] table

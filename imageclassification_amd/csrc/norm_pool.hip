@@ -61,6 +61,22 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* _
   if (c < C) {
     double u1 = 0.0, u2 = 0.0;
     int r = r0 + rl;
+    // Round 4: 16 rows (32 loads) requested at once, then added in the SAME order as the loop below adds them (the two
+    // accumulator pairs take alternate rows): bit-identical sums, one L2 round trip instead of eight for a 512-row table --
+    // these 106 launches per ResNet-50 step are a dependent latency chain, 7.3 / 6.1 us each for <= 3 MB of partial rows.
+    constexpr int UN = 8;
+    for (; r + (2 * UN - 1) * RL < r1; r += 2 * UN * RL) {
+      float a0[UN], a1[UN], b0[UN], b1[UN];
+#pragma unroll
+      for (int k = 0; k < UN; ++k) {
+        a0[k] = part[((long long)(r + 2 * k * RL) * 2 + 0) * C + c];
+        a1[k] = part[((long long)(r + 2 * k * RL) * 2 + 1) * C + c];
+        b0[k] = part[((long long)(r + (2 * k + 1) * RL) * 2 + 0) * C + c];
+        b1[k] = part[((long long)(r + (2 * k + 1) * RL) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int k = 0; k < UN; ++k) { s1 += (double)a0[k]; s2 += (double)a1[k]; u1 += (double)b0[k]; u2 += (double)b1[k]; }
+    }
     for (; r + RL < r1; r += 2 * RL) {
       const float a0 = part[((long long)r * 2 + 0) * C + c], a1 = part[((long long)r * 2 + 1) * C + c];
       const float b0 = part[((long long)(r + RL) * 2 + 0) * C + c], b1 = part[((long long)(r + RL) * 2 + 1) * C + c];
