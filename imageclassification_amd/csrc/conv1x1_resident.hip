@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int Y_WAVE = (BNR || EXT) ? MF * 16 * EROW : 0;
   static_assert(!BNR || (ADD && NF == 4 && WN == 4 && !EXT), "bnred: 256-channel workgroups with an addend");
   constexpr int X_BYTES = 0;
-  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + 4 * Y_WAVE + X_BYTES];
+  constexpr int YB = EXT ? 2 : 1;                    // EXT: the z patch of the NEXT tile travels with that tile's activations
+  static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES];
   f32x4 gacc[ABL ? 8 : 1];   // (8, not the 16 a [256][64] gradient needs: with 16 the kernel spills and every reload drains the LDS-DMA queue)
   if constexpr (ABL) {
 #pragma unroll
@@ -122,8 +123,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, 0);
     }
   };
+  // EXT, data gradient x gelu'(z): this wave's [MF*16 rows][CW] sub-tile of z, staged ONE TILE AHEAD with the activations (round 4,
+  // second form: issued at the start of its own tile the patch had only the tile's 64 MFMAs to land under and the store pass waited
+  // for it -- 188 us at K = 192 either way; the loop-top wait that retires the tile's activations retires the patch with them)
+  auto stage_z = [&](int tm0, int buf) {
+    if constexpr (EXT) {
+      if (p.gelu_z != nullptr) {
+        constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;
+        unsigned char* const dst = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + (buf * 4 + wave) * Y_WAVE;
+        const int mwz = tm0 + wm * MF * 16;
+#pragma unroll
+        for (int q = 0; q < Y_WAVE / 1024; ++q) {
+          const int row = q * RPIA + lane / LPRA, pos = lane % LPRA;
+          const int chunk = pos ^ (row & (LPRA - 1));
+          const int m = mwz + row;
+          const bf16_t* src = m < p.M ? p.gelu_z + ((long long)m * p.N + n0 + chunk * 8) : zero;
+          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + q * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
   int m0 = m_begin;
-  if (m0 < m_end) stage(m0, 0);                 // in flight under the filter loads
+  if (m0 < m_end) { stage(m0, 0); stage_z(m0, 0); }   // in flight under the filter loads
 
   // ---- the filter: fragment (ks, j) = rows n0 + j*16 + fr, 8 input channels at ks*32 + fq*8
   bf16x8 wf[KS][NF];
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     unsigned long long pbw[BNR ? MF : 1];          // BNR: the previous block's ReLU mask words of this lane's rows
     bool has_add = false;
     unsigned char* const sP = smem + 2 * A_BYTES + 4 * E_WAVE + wave * P_WAVE;
-    unsigned char* const sY = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + wave * Y_WAVE;
+    unsigned char* const sY = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + ((EXT ? BUF * 4 : 0) + wave) * Y_WAVE;
     if constexpr (ADD) {
       has_add = true;
       constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;      // lanes per patch row, rows per instruction
@@ -232,19 +253,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
         }
       }
     }
-    if constexpr (EXT) {
-      if (p.gelu_z != nullptr) {
-        constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;
-#pragma unroll
-        for (int q = 0; q < Y_WAVE / 1024; ++q) {
-          const int row = q * RPIA + lane / LPRA, pos = lane % LPRA;
-          const int chunk = pos ^ (row & (LPRA - 1));
-          const int m = mw + row;
-          const bf16_t* src = m < p.M ? p.gelu_z + ((long long)m * p.N + n0 + chunk * 8) : zero;
-          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sY + q * 1024), 16, 0, 0);
-        }
-      }
-    }
     static_for<0, KS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
       bf16x8 xf[MF];
@@ -287,9 +295,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     }
     // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
     if constexpr (ADD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's addend patch (and bit words) landed
-    if constexpr (EXT) {
-      if (p.gelu_z != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's z patch landed
-    }
     static_for<0, (MF + 1) / 2>([&](auto hc) {
       constexpr int h = decltype(hc)::value;
 #pragma unroll
@@ -397,13 +402,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     wait_tile_loads();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (m0 + TM < m_end) stage(m0 + TM, 1);
+    if (m0 + TM < m_end) { stage(m0 + TM, 1); stage_z(m0 + TM, 1); }
     tile(std::integral_constant<int, 0>{}, m0);
     if (m0 + TM >= m_end) break;
     wait_tile_loads();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (m0 + 2 * TM < m_end) stage(m0 + 2 * TM, 0);
+    if (m0 + 2 * TM < m_end) { stage(m0 + 2 * TM, 0); stage_z(m0 + 2 * TM, 0); }
     tile(std::integral_constant<int, 1>{}, m0 + TM);
   }
 
@@ -539,14 +544,20 @@ int icamd_pw_resident_bnred_launch(PwResidentParams& p, hipStream_t stream) {
 // 64-wide stages of conv_igemm / gemm_nt and ran on conv_igemm's general-channel path at 391 us per launch at batch 256
 // (M = 802 816; 0.77-1.4 GB of HBM traffic: 120-220 us).  Here it is four 32-wide k-steps over 256 B staged rows.
 bool icamd_pw_resident_ext_wanted(long long M, int N, int K) {
-  return mode() != 0 && K == 96 && N % 128 == 0 && M >= 8192 && M < (1ll << 30);
+  if (mode() == 0 || M < 8192 || M >= (1ll << 30)) return false;
+  if (K == 96 && N % 128 == 0) return true;
+  // round 4: K = 192 (ConvNeXt-T stage 1: 192 -> 768 forward + GELU, data gradient of 768 -> 192 + GELU') as eight k-steps over
+  // 512 B staged rows, 256 channels per workgroup.  ICAMD_PW_EXT192=0: back on conv_igemm.
+  static const int k192 = [] { const char* e = getenv("ICAMD_PW_EXT192"); return e ? atoi(e) : 1; }();
+  return k192 && K == 192 && N % 256 == 0;
 }
 
 int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   if (!icamd_pw_resident_ext_wanted(p.M, p.N, p.K) || p.addend != nullptr || p.stats != nullptr) return ICAMD_ERR_UNSUPPORTED;
-  p.lda = p.K; p.Ktrue = p.K; p.K = 128;
-  constexpr int tm = 64;                         // <4, 2, 4, 4>: 64 rows x 128 channels per workgroup
-  p.ntiles_n = p.N / 128;
+  const bool k96 = p.K == 96;
+  p.lda = p.K; p.Ktrue = p.K; p.K = k96 ? 128 : 256;
+  const int tm = k96 ? 64 : 32;                  // <4, 2, 4, 4>: 64 rows x 128 channels per workgroup; <8, 4, 2, 4>: 32 x 256
+  p.ntiles_n = p.N / (k96 ? 128 : 256);
   const int wgs = 2 * icamd_num_cus();
   int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
   const int cap_tiles = (p.M + tm - 1) / tm;
@@ -557,7 +568,8 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   p.rows_per_split = rows;
   S = (p.M + rows - 1) / rows;
   p.xcd_groups = xcd_order();
-  hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
+  if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv1x1_resident_kernel<8, 4, 2, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
   return icamd_launch_status();
 }
 

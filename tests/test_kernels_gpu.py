@@ -355,7 +355,10 @@ def test_conv_fwd_act_and_bn_fold(lib, case):
                                   # ConvNeXt-T's dim-96 Linear layers on the register-resident kernel's K = 96 form (four k-steps
                                   # over 256 B staged rows, zero filter columns; csrc/conv1x1_resident.hip EXT): forward of
                                   # 96 -> 384 and data gradient of 384 -> 96, ragged last tile
-                                  (8, 40, 41, 96, 384), (8, 40, 41, 384, 96)])
+                                  (8, 40, 41, 96, 384), (8, 40, 41, 384, 96),
+                                  # round 4: the K = 192 form (eight k-steps over 512 B staged rows, 256 channels per workgroup):
+                                  # forward of 192 -> 768 and data gradient of 768 -> 192, ragged last tile
+                                  (6, 40, 41, 192, 768), (6, 40, 41, 768, 192)])
 def test_pointwise_gelu_epilogues(lib, case):
     """fc1 forward with GELU in the store pass and fc2 data gradient with the GELU backward in the store pass are
     bit-identical to the two-kernel sequences they replace (and those are oracle-checked elsewhere); both GEMM kernels
