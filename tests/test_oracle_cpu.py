@@ -569,3 +569,37 @@ def test_loss_curve_fixture_is_the_live_oracles_curve():
     assert abs(tr[0]["loss"] - doc["oracle"][0]) <= 1e-5 * doc["oracle"][0], (tr[0]["loss"], doc["oracle"][0])
     assert abs(tr[1]["loss"] - doc["oracle"][1]) <= 1e-4 * doc["oracle"][1], (tr[1]["loss"], doc["oracle"][1])
     assert abs(doc["oracle_fp64"][0] - doc["oracle"][0]) <= 1e-3 * doc["oracle"][0]
+
+
+@pytest.mark.parametrize("name,batch", [("r04_bench_n1.json", 256), ("r04_bench_eval.json", 384), ("r04_bench_vit.json", 256),
+                                        ("r04_bench_convnext.json", 256)])
+def test_committed_bench_lines_keep_the_contract(name, batch):
+    """The bench lines committed under profiles/ (what bench.py printed on the MI355X box) carry every field of the driver's
+    contract and are self-consistent: value = batch / ms_per_step, roofline.frac = achieved / peak, roofline.kernel is the class
+    with the largest time of ALL classes, the blended step is the sum of the classes' algorithmic work over the timed step, and
+    the PMC summary the traffic came from is stamped with the same kernel-source hash as the line."""
+    d = json.loads(open(os.path.join(ROOT, "profiles", name)).readline())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_classes", "roofline_step", "host_enqueue_ms", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - batch * d["n_gpus"] * 1e3 / d["ms_per_step"]) <= 2e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    assert r["peak"] == (8000.0 if r["bound"] == "hbm" else 2500.0) and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3
+    cls = d["roofline_classes"]
+    assert r["kernel"] == max(cls, key=lambda k: cls[k]["ms_per_step"])
+    assert isinstance(r["traffic"], int) and r["traffic"] > 0      # committed lines were printed with the PMC summary in place
+    step = d["roofline_step"]
+    assert abs(step["algorithmic_GB"] - sum(c["algorithmic_GB_per_step"] for c in cls.values())) <= 0.05
+    assert abs(step["hbm_frac"] - step["algorithmic_GB"] / (d["ms_per_step"] * 1e-3) / 8000.0) <= 2e-3
+    assert 0.0 < d["host_enqueue_ms"] < d["ms_per_step"]
+    if name in ("r04_bench_n1.json", "r04_bench_eval.json"):
+        cb = d["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    pmc = {"r04_bench_n1.json": "r04_pmc_traffic.json", "r04_bench_eval.json": "r04_pmc_traffic_eval.json",
+           "r04_bench_vit.json": "r04_pmc_traffic_vit.json", "r04_bench_convnext.json": "r04_pmc_traffic_convnext.json"}[name]
+    assert json.load(open(os.path.join(ROOT, "profiles", pmc)))["kernel_source_hash"] == d["kernel_source_hash"]
