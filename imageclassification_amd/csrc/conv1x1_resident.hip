@@ -41,7 +41,9 @@ namespace {
 // data-gradient + weight-gradient kernel before building it -- per tile one more 8 KB LDS-DMA (the x tile,
 // read from real memory: the dx buffer), 32 transposed LDS reads and 32 more MFMAs per wave into 16 more accumulators (a
 // [256][64] fp32 filter gradient over four waves); results are garbage and unused.
-template <int KS, int NF, int MF, int WN, bool ADD, bool EXT = false, bool BNR = false, bool EPI = false, bool ABL = false>
+// EXT: 0 = off, 1 = with the z patch of the "x gelu'(z)" form, 2 = forward forms only (no z patch: the LDS it would take buys
+// twice the rows per tile instead)
+template <int KS, int NF, int MF, int WN, bool ADD, int EXT = 0, bool BNR = false, bool EPI = false, bool ABL = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
@@ -58,10 +60,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   // BNR: the same shape for the BatchNorm input y.  EXT (round 4): the same patch carries the pre-GELU activations z of the
   // "data gradient x gelu'(z)" form: read per row group from global memory inside the store pass they cost a full load latency
   // four times per tile (455 us for 1.39 GB at ConvNeXt-T's stage 0); as a patch they land under the MFMAs.
-  constexpr int Y_WAVE = (BNR || EXT) ? MF * 16 * EROW : 0;
+  constexpr int Y_WAVE = (BNR || EXT == 1) ? MF * 16 * EROW : 0;
   static_assert(!BNR || (ADD && NF == 4 && WN == 4 && !EXT), "bnred: 256-channel workgroups with an addend");
   constexpr int X_BYTES = 0;
-  constexpr int YB = EXT ? 2 : 1;                    // EXT: the z patch of the NEXT tile travels with that tile's activations
+  constexpr int YB = EXT == 1 ? 2 : 1;                    // EXT: the z patch of the NEXT tile travels with that tile's activations
   static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES];
   f32x4 gacc[ABL ? 8 : 1];   // (8, not the 16 a [256][64] gradient needs: with 16 the kernel spills and every reload drains the LDS-DMA queue)
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   // second form: issued at the start of its own tile the patch had only the tile's 64 MFMAs to land under and the store pass waited
   // for it -- 188 us at K = 192 either way; the loop-top wait that retires the tile's activations retires the patch with them)
   auto stage_z = [&](int tm0, int buf) {
-    if constexpr (EXT) {
+    if constexpr (EXT == 1) {
       if (p.gelu_z != nullptr) {
         constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;
         unsigned char* const dst = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + (buf * 4 + wave) * Y_WAVE;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
     unsigned long long pbw[BNR ? MF : 1];          // BNR: the previous block's ReLU mask words of this lane's rows
     bool has_add = false;
     unsigned char* const sP = smem + 2 * A_BYTES + 4 * E_WAVE + wave * P_WAVE;
-    unsigned char* const sY = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + ((EXT ? BUF * 4 : 0) + wave) * Y_WAVE;
+    unsigned char* const sY = smem + 2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + ((EXT == 1 ? BUF * 4 : 0) + wave) * Y_WAVE;
     if constexpr (ADD) {
       has_add = true;
       constexpr int LPRA = EROW / 16, RPIA = 64 / LPRA;      // lanes per patch row, rows per instruction
@@ -353,9 +355,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           if (m < m_end) {
             if constexpr (EXT) {
               const long long off = (long long)m * p.N + n0 + c * 8;
-              if (p.gelu_z != nullptr) {
-                const int pr = i * 16 + rr;                  // row of the wave's z patch; chunk c sits at c ^ (row & (LPR - 1))
-                o = gelu_bwd8(o, *(const u32x4*)(sY + pr * EROW + (((c ^ pr) & (LPR - 1)) << 4)));
+              if constexpr (EXT == 1) {
+                if (p.gelu_z != nullptr) {
+                  const int pr = i * 16 + rr;                // row of the wave's z patch; chunk c sits at c ^ (row & (LPR - 1))
+                  o = gelu_bwd8(o, *(const u32x4*)(sY + pr * EROW + (((c ^ pr) & (LPR - 1)) << 4)));
+                }
               }
               if (p.gelu_inplace) o = gelu8(o);
               if (p.gelu_out != nullptr) *(u32x4*)(p.gelu_out + off) = gelu8(o);
@@ -555,8 +559,13 @@ bool icamd_pw_resident_ext_wanted(long long M, int N, int K) {
 int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   if (!icamd_pw_resident_ext_wanted(p.M, p.N, p.K) || p.addend != nullptr || p.stats != nullptr) return ICAMD_ERR_UNSUPPORTED;
   const bool k96 = p.K == 96;
+  // K = 96 forward forms (bias / GELU, no z to read): 128-row tiles.  After the latency fixes of round 4 these kernels are bound by
+  // their per-tile chain (barrier -> LDS transposition -> GELU -> stores), so rows per barrier are what counts; the LDS the z patch
+  // would take pays for the second half of the tile.  ICAMD_PW_EXT_TM128=0: 64-row tiles for every form.
+  static const int tm128 = [] { const char* e = getenv("ICAMD_PW_EXT_TM128"); return e ? atoi(e) : 1; }();
+  const bool big = k96 && p.gelu_z == nullptr && tm128 != 0;
   p.lda = p.K; p.Ktrue = p.K; p.K = k96 ? 128 : 256;
-  const int tm = k96 ? 64 : 32;                  // <4, 2, 4, 4>: 64 rows x 128 channels per workgroup; <8, 4, 2, 4>: 32 x 256
+  const int tm = k96 ? (big ? 128 : 64) : 32;    // <4, 2, 4|8, 4>: 64 | 128 rows x 128 channels per workgroup; <8, 4, 2, 4>: 32 x 256
   p.ntiles_n = p.N / (k96 ? 128 : 256);
   const int wgs = 2 * icamd_num_cus();
   int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
@@ -568,8 +577,10 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   p.rows_per_split = rows;
   S = (p.M + rows - 1) / rows;
   p.xcd_groups = xcd_order();
-  if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv1x1_resident_kernel<8, 4, 2, 4, false, true>), dim3((unsigned)(S * p.ntiles_n)), dim3(256), 0, stream, p);
+  const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
+  if (big) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 8, 4, false, 2>), grid, block, 0, stream, p);
+  else if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 1>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((conv1x1_resident_kernel<8, 4, 2, 4, false, 1>), grid, block, 0, stream, p);
   return icamd_launch_status();
 }
 
