@@ -44,7 +44,7 @@ namespace {
 // EXT: 0 = off, 1 = with the z patch of the "x gelu'(z)" form, 2 = forward forms only (no z patch: the LDS it would take buys
 // twice the rows per tile instead)
 template <int KS, int NF, int MF, int WN, bool ADD, int EXT = 0, bool BNR = false, bool EPI = false, bool ABL = false>
-__global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
+__global__ __launch_bounds__(256, (EXT == 2 && MF == 4) ? 3 : 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
   constexpr int ROWB = KS * 64;                 // bytes per activation row
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   constexpr int X_BYTES = 0;
   constexpr int YB = EXT == 1 ? 2 : 1;                    // EXT: the z patch of the NEXT tile travels with that tile's activations
   static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
+  static_assert(!(EXT == 2 && MF == 4) || 3 * (2 * A_BYTES + 4 * E_WAVE) <= 160 * 1024, "three workgroups per CU");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES];
   f32x4 gacc[ABL ? 8 : 1];   // (8, not the 16 a [256][64] gradient needs: with 16 the kernel spills and every reload drains the LDS-DMA queue)
   if constexpr (ABL) {
@@ -563,11 +564,14 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   // their per-tile chain (barrier -> LDS transposition -> GELU -> stores), so rows per barrier are what counts; the LDS the z patch
   // would take pays for the second half of the tile.  ICAMD_PW_EXT_TM128=0: 64-row tiles for every form.
   static const int tm128 = [] { const char* e = getenv("ICAMD_PW_EXT_TM128"); return e ? atoi(e) : 1; }();
-  const bool big = k96 && p.gelu_z == nullptr && tm128 != 0;
+  // ICAMD_PW_EXT_TM128=2: the other way to spend that LDS -- 64-row tiles, THREE workgroups per CU (40 KB and 138 VGPRs each):
+  // measured a wash (z + gelu(z) 362 -> 373 us, gelu(z) only 297 -> 279 us), kept as a switch only
+  const bool big = k96 && p.gelu_z == nullptr && tm128 == 1;
+  const bool three = k96 && p.gelu_z == nullptr && tm128 == 2;
   p.lda = p.K; p.Ktrue = p.K; p.K = k96 ? 128 : 256;
   const int tm = k96 ? (big ? 128 : 64) : 32;    // <4, 2, 4|8, 4>: 64 | 128 rows x 128 channels per workgroup; <8, 4, 2, 4>: 32 x 256
   p.ntiles_n = p.N / (k96 ? 128 : 256);
-  const int wgs = 2 * icamd_num_cus();
+  const int wgs = (three ? 3 : 2) * icamd_num_cus();
   int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
   const int cap_tiles = (p.M + tm - 1) / tm;
   if (S > cap_tiles) S = cap_tiles;
@@ -579,6 +583,7 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   p.xcd_groups = xcd_order();
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (big) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 8, 4, false, 2>), grid, block, 0, stream, p);
+  else if (three) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 2>), grid, block, 0, stream, p);
   else if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 1>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((conv1x1_resident_kernel<8, 4, 2, 4, false, 1>), grid, block, 0, stream, p);
   return icamd_launch_status();
