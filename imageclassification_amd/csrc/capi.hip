@@ -983,10 +983,12 @@ int icamd_stem7x7s2_fwd(const void* x4, const void* w, void* y, const float* bia
   if (x4 == nullptr || w == nullptr || y == nullptr || !stem_shape_ok(N, H, W, Cout)) return ICAMD_ERR_BAD_ARG;
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;   // (H + 6 - 7) / 2 + 1
   if ((long long)N * OH * OW >= (1ll << 31)) return ICAMD_ERR_UNSUPPORTED;
-  if (bias == nullptr && !relu && icamd_stem_resident_wanted(N, H, W, Cout)) {   // training form: conv_stem.hip
+  // conv_stem.hip: the training form (statistics) and, round 4, the inference form (bias + ReLU, no statistics)
+  if ((stats == nullptr || (bias == nullptr && !relu)) && icamd_stem_resident_wanted(N, H, W, Cout)) {
     StemParams sp;
     memset(&sp, 0, sizeof(sp));
     sp.x = (const bf16_t*)x4; sp.w = (const bf16_t*)w; sp.y = (bf16_t*)y; sp.stats = stats; sp.N = N; sp.H = H; sp.W = W;
+    sp.bias = bias; sp.relu = relu;
     return icamd_stem_resident_launch(sp, (hipStream_t)stream);
   }
   IgemmParams p;

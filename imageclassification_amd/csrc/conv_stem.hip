@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_resident_kernel(const StemPa
 #pragma unroll
   for (int e = 0; e < 4; ++e) { s1[e] = f32x2{0.f, 0.f}; s2[e] = f32x2{0.f, 0.f}; }
   const bool want_stats = p.stats != nullptr;
+  const bool epi = p.bias != nullptr || p.relu;          // uniform
+  f32x4 bias4[2];                                         // MFMA layout: a lane owns channels wn*32 + j*16 + 4*fq .. +3
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    bias4[j] = p.bias != nullptr ? *(const f32x4*)(p.bias + wn * 32 + j * 16 + 4 * fq) : f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto do_tile = [&](auto bufc, int t) {
     constexpr int BUF = decltype(bufc)::value;
@@ -112,7 +117,14 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_resident_kernel(const StemPa
         if (i < MF) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const f32x4 v = acc[j][i];
+            f32x4 v = acc[j][i];
+            if (epi) {   // inference (round 4): + folded BatchNorm shift, ReLU, one rounding -- evaluate()'s stem ran on conv_igemm
+              v += bias4[j];
+              if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+              }
+            }
             u32x2 pk;
             pk[0] = pack_bf16x2(v[0], v[1]);
             pk[1] = pack_bf16x2(v[2], v[3]);

@@ -125,6 +125,8 @@ struct StemParams {
   bf16_t* y;         // [N][OH][OW][64]
   float* stats;      // optional [ceil(M/128)][2][64]
   int N, H, W, OH, OW;
+  const float* bias; // optional [64]: inference epilogue (folded BatchNorm shift)
+  int relu;
 };
 struct StemWgradParams {
   const bf16_t* x;   // [N][H][W+8][4]
