@@ -174,6 +174,19 @@ static inline int icamd_num_cus() {
   return n;
 }
 
+// XCDs (XCCs) of the current device as the runtime reports them: 8 on an MI355X in its default (SPX) mode.  The XCD-aware
+// workgroup orders assume round-robin dispatch over exactly 8 XCDs; they are bijections on any device (correctness never depends
+// on them) and are switched off when the count differs (CPX / partitioned modes, other parts).  0 if the query fails.
+static inline int icamd_num_xccs() {
+  static const int n = [] {
+    int dev = 0, x = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || x <= 0) return 0;
+    return x;
+  }();
+  return n;
+}
+
 static inline int icamd_launch_status() {
   return hipGetLastError() == hipSuccess ? ICAMD_OK : ICAMD_ERR_LAUNCH;
 }

@@ -37,14 +37,12 @@ namespace {
 // read of dout and y) disappears for that BatchNorm; this kernel reads y once instead.
 // EPI (round 4): the inference epilogue of evaluate()'s BatchNorm-folded forward (engine.py:145-225): + bias[n] in fp32, + addend
 // (the ADD patch), ReLU, ONE rounding -- the arithmetic of conv_igemm's fused epilogue, which these launches used to run on.
-// ABL (round 4, measurement only, ICAMD_PW_ABLATE_WGRAD=1 on the K = 256 / N = 64 data gradient): the cost model of a fused
-// data-gradient + weight-gradient kernel before building it -- per tile one more 8 KB LDS-DMA (the x tile,
-// read from real memory: the dx buffer), 32 transposed LDS reads and 32 more MFMAs per wave into 16 more accumulators (a
-// [256][64] fp32 filter gradient over four waves); results are garbage and unused.
+// (round 4's ABL instantiation -- the cost model of a fused data-gradient + weight-gradient kernel, profiles/r04_ablate_fused_dgrad_wgrad.txt --
+// was measurement-only code and left the product in round 5; `git show 08b0279:imageclassification_amd/csrc/conv1x1_resident.hip` has it.)
 // EXT: 0 = off, 1 = with the z patch of the "x gelu'(z)" form, 2 = forward forms only (no z patch: the LDS it would take buys
 // twice the rows per tile instead)
-template <int KS, int NF, int MF, int WN, bool ADD, int EXT = 0, bool BNR = false, bool EPI = false, bool ABL = false>
-__global__ __launch_bounds__(256, (EXT == 2 && MF == 4) ? 3 : 2) void conv1x1_resident_kernel(const PwResidentParams p) {
+template <int KS, int NF, int MF, int WN, bool ADD, int EXT = 0, bool BNR = false, bool EPI = false>
+__global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwResidentParams p) {
   constexpr int WM = 4 / WN;
   constexpr int TM = WM * MF * 16;              // rows per tile
   constexpr int ROWB = KS * 64;                 // bytes per activation row
@@ -65,14 +63,7 @@ __global__ __launch_bounds__(256, (EXT == 2 && MF == 4) ? 3 : 2) void conv1x1_re
   constexpr int X_BYTES = 0;
   constexpr int YB = EXT == 1 ? 2 : 1;                    // EXT: the z patch of the NEXT tile travels with that tile's activations
   static_assert(2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES <= 80 * 1024, "two workgroups per CU");
-  static_assert(!(EXT == 2 && MF == 4) || 3 * (2 * A_BYTES + 4 * E_WAVE) <= 160 * 1024, "three workgroups per CU");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 4 * E_WAVE + 4 * P_WAVE + YB * 4 * Y_WAVE + X_BYTES];
-  f32x4 gacc[ABL ? 8 : 1];   // (8, not the 16 a [256][64] gradient needs: with 16 the kernel spills and every reload drains the LDS-DMA queue)
-  if constexpr (ABL) {
-#pragma unroll
-    for (int f = 0; f < 8; ++f) gacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
@@ -119,9 +110,10 @@ __global__ __launch_bounds__(256, (EXT == 2 && MF == 4) ? 3 : 2) void conv1x1_re
       const int m = m0 + row;
       const bf16_t* src = m < m_end ? p.A + ((long long)m * p.K + chunk * 8) : zero;
       if constexpr (EXT) {
-        // columns >= Ktrue of a row are the first columns of the NEXT row (multiplied by zero filter columns): real memory
-        // except behind the very last row
-        src = (m < m_end && (chunk * 8 < p.Ktrue || m + 1 < p.M)) ? p.A + ((long long)m * p.lda + chunk * 8) : zero;
+        // columns >= Ktrue of a staged row come from the zero page (round 5, ADVICE r4: read as the first columns of the NEXT row
+        // and multiplied by the zero filter columns, one Inf / NaN in row m + 1 -- possibly the next image -- poisoned every output
+        // channel of row m; a Linear layer keeps a non-finite value in its own row).  Same number of LDS-DMA instructions.
+        src = (m < m_end && chunk * 8 < p.Ktrue) ? p.A + ((long long)m * p.lda + chunk * 8) : zero;
       }
       __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, 0);
     }
@@ -271,31 +263,6 @@ __global__ __launch_bounds__(256, (EXT == 2 && MF == 4) ? 3 : 2) void conv1x1_re
       });
     });
 
-    if constexpr (ABL) {
-      // (second form of the ablation: no x-tile DMA -- its 103 MB are priced separately -- and no mid-tile wait: the first form
-      // drained the NEXT tile's staging loads with a vmcnt(0) and ran 321 us; both operands are read from the dy tile)
-      unsigned char* const sX = smem + BUF * A_BYTES + 256;
-      typedef bf16x4 __attribute__((address_space(3))) * lp4;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 bfr[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          const unsigned char* pb = sX + (kk * 32 + (lane & 15)) * ROWB + f * 32 + (lane >> 4) * 8;
-          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)pb), b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(pb + 16 * ROWB));
-          bfr[f] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        }
-#pragma unroll
-        for (int fa = 0; fa < 4; ++fa) {
-          const unsigned char* pa = smem + BUF * A_BYTES + (kk * 32 + (lane & 15)) * ROWB + (wave * 4 + fa) * 32 + (lane >> 4) * 8;
-          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)pa), a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(pa + 16 * ROWB));
-          const bf16x8 af = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-#pragma unroll
-          for (int fb = 0; fb < 4; ++fb)
-            gacc[(fa & 1) * 4 + fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[fb], gacc[(fa & 1) * 4 + fb], 0, 0, 0);
-        }
-      }
-    }
     // ---- epilogue, wave-private, two row fragments at a time through the wave's LDS patches
     if constexpr (ADD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's addend patch (and bit words) landed
     static_for<0, (MF + 1) / 2>([&](auto hc) {
@@ -417,10 +384,6 @@ __global__ __launch_bounds__(256, (EXT == 2 && MF == 4) ? 3 : 2) void conv1x1_re
     tile(std::integral_constant<int, 1>{}, m0 + TM);
   }
 
-  if constexpr (ABL) {
-#pragma unroll
-    for (int f = 0; f < 8; ++f) asm volatile("" ::"v"(gacc[f]));
-  }
   if (want_stats) {
     // one partial row per workgroup (row `split` of the [ceil(M/128)] table); rows no workgroup owns are zero
     __syncthreads();
@@ -454,8 +417,8 @@ int mode() {
   static const int m = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e ? atoi(e) : 1; }();
   return m;
 }
-int xcd_order() {   // ICAMD_PW_XCD=0: the consecutive numbering of rounds 2-3 (A/B runs)
-  static const int m = [] { const char* e = getenv("ICAMD_PW_XCD"); return e ? atoi(e) : 1; }();
+int xcd_order() {   // ICAMD_PW_XCD=0: the consecutive numbering of rounds 2-3 (A/B runs); off when the device does not report 8 XCDs
+  static const int m = [] { const char* e = getenv("ICAMD_PW_XCD"); return (e ? atoi(e) : 1) && icamd_num_xccs() == 8; }();
   return m;
 }
 
@@ -492,14 +455,6 @@ int launch(const PwResidentParams& p, int grid, hipStream_t stream) {
     if constexpr (KS == 8 && NF == 2 && WN == 4) return ICAMD_ERR_UNSUPPORTED;
     else hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   } else {
-    if constexpr (KS == 8 && NF == 2 && MF == 2 && WN == 2) {
-      static const int abl = [] { const char* e = getenv("ICAMD_PW_ABLATE_WGRAD"); return e ? atoi(e) : 0; }();
-      if (abl && p.stats == nullptr) {
-        hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false, false, false, false, true>), dim3((unsigned)grid), dim3(256), 0,
-                           stream, p);
-        return icamd_launch_status();
-      }
-    }
     hipLaunchKernelGGL((conv1x1_resident_kernel<KS, NF, MF, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
   }
   return icamd_launch_status();
@@ -564,14 +519,12 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   // their per-tile chain (barrier -> LDS transposition -> GELU -> stores), so rows per barrier are what counts; the LDS the z patch
   // would take pays for the second half of the tile.  ICAMD_PW_EXT_TM128=0: 64-row tiles for every form.
   static const int tm128 = [] { const char* e = getenv("ICAMD_PW_EXT_TM128"); return e ? atoi(e) : 1; }();
-  // ICAMD_PW_EXT_TM128=2: the other way to spend that LDS -- 64-row tiles, THREE workgroups per CU (40 KB and 138 VGPRs each):
-  // measured a wash (z + gelu(z) 362 -> 373 us, gelu(z) only 297 -> 279 us), kept as a switch only
+  // (64-row tiles at THREE workgroups per CU -- 40 KB and 138 VGPRs each -- measured a wash in round 4 and are gone)
   const bool big = k96 && p.gelu_z == nullptr && tm128 == 1;
-  const bool three = k96 && p.gelu_z == nullptr && tm128 == 2;
   p.lda = p.K; p.Ktrue = p.K; p.K = k96 ? 128 : 256;
   const int tm = k96 ? (big ? 128 : 64) : 32;    // <4, 2, 4|8, 4>: 64 | 128 rows x 128 channels per workgroup; <8, 4, 2, 4>: 32 x 256
   p.ntiles_n = p.N / (k96 ? 128 : 256);
-  const int wgs = (three ? 3 : 2) * icamd_num_cus();
+  const int wgs = 2 * icamd_num_cus();
   int S = (wgs + p.ntiles_n - 1) / p.ntiles_n;
   const int cap_tiles = (p.M + tm - 1) / tm;
   if (S > cap_tiles) S = cap_tiles;
@@ -583,7 +536,6 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   p.xcd_groups = xcd_order();
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (big) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 8, 4, false, 2>), grid, block, 0, stream, p);
-  else if (three) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 2>), grid, block, 0, stream, p);
   else if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 1>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((conv1x1_resident_kernel<8, 4, 2, 4, false, 1>), grid, block, 0, stream, p);
   return icamd_launch_status();

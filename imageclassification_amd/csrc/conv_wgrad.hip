@@ -31,6 +31,32 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* p0, const un
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+// Workgroup -> (output tile, pixel split).  Dispatch is round-robin over the 8 XCDs (blocks b and b + 8 share one; speed only,
+// never correctness): XCD x runs blocks x, x + 8, ... in that order.
+//   xcd_chunk = 1 (round 5): the split-major list L = split * tiles + tile is cut into 8 CONTIGUOUS chunks, one per XCD, walked in
+//     dispatch order -- an XCD works on at most two neighbouring splits at a time and every tile of a split that it owns reads the
+//     split's pixel rows from ITS L2.  This is a bijection for any grid size.
+//   xcd_chunk = 0 (rounds 1-4): groups of 8 consecutive splits, the split as the low 3 bits of the block id inside a group.  Right
+//     only while S is a multiple of 8: with S = 7 (ViT-B/16's 768 x 3072 weight gradients: 36 tiles of 256 x 256, one workgroup per
+//     CU) block b = tile * 7 + split lands on XCD (tile * 7 + split) % 8, every split's tiles are spread over all eight L2s and each
+//     of them fetches the split's rows again: PMC 891 MB fetched per launch for 310 MB of operands (profiles/r04_pmc_traffic_vit.json).
+__device__ __forceinline__ void wgrad_block_order(const WgradParams& p, unsigned int& tile, int& split) {
+  const unsigned int nt = (unsigned)(p.ntiles_k * p.ntiles_c);
+  if (p.xcd_chunk) {
+    const unsigned int nblk = gridDim.x, xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned int q = nblk >> 3, r = nblk & 7u;
+    const unsigned int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    split = (int)(L / nt);
+    tile = L - (unsigned)split * nt;
+    return;
+  }
+  const unsigned int grp = blockIdx.x / (8u * nt);
+  const unsigned int rem = blockIdx.x - grp * 8u * nt;
+  const unsigned int ns = min(8u, (unsigned)p.S - grp * 8u);
+  tile = rem / ns;
+  split = (int)(grp * 8u + (rem - tile * ns));
+}
+
 #ifndef ICAMD_WGRAD_STAGES
 #define ICAMD_WGRAD_STAGES 1   // 1: single LDS stage + 3-4 workgroups per CU; 2: double buffer
 #endif
@@ -54,15 +80,11 @@ __global__ __launch_bounds__(256, (ICAMD_WGRAD_STAGES == 1 ? ICAMD_WGRAD_WAVES_P
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wc = wave >> 1;
 
-  // Block order: 8 consecutive pixel splits form a group; inside a group block ids go tile-major with the split as the
-  // low 3 bits, so (blocks b and b+8 share an XCD) all output tiles of one split run on ONE XCD at about the same time and
-  // the split's dY / X pixels are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
-  const unsigned int nt = (unsigned)(p.ntiles_k * p.ntiles_c);
-  const unsigned int grp = blockIdx.x / (8u * nt);
-  const unsigned int rem = blockIdx.x - grp * 8u * nt;
-  const unsigned int ns = min(8u, (unsigned)p.S - grp * 8u);
-  const unsigned int tile = rem / ns;
-  const int split = (int)(grp * 8u + (rem - tile * ns));
+  // Block order (wgrad_block_order): all output tiles of one pixel split run on ONE XCD at about the same time, so the split's
+  // dY / X pixels are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
+  unsigned int tile;
+  int split;
+  wgrad_block_order(p, tile, split);
   const int tile_c = (int)(tile % (unsigned)p.ntiles_c);
   const int tile_k = (int)(tile / (unsigned)p.ntiles_c);
   const int k0 = tile_k * BMK, c0 = tile_c * BNC;
@@ -289,12 +311,9 @@ __global__ __launch_bounds__(64 * WK * WC, WPS) void conv_wgrad_ring_kernel(cons
   const int wk = wave % WK, wc = wave / WK;
 
   // block order: see conv_wgrad_kernel (all tiles of one pixel split on one XCD)
-  const unsigned int nt = (unsigned)(p.ntiles_k * p.ntiles_c);
-  const unsigned int grp = blockIdx.x / (8u * nt);
-  const unsigned int rem = blockIdx.x - grp * 8u * nt;
-  const unsigned int ns = min(8u, (unsigned)p.S - grp * 8u);
-  const unsigned int tile = rem / ns;
-  const int split = (int)(grp * 8u + (rem - tile * ns));
+  unsigned int tile;
+  int split;
+  wgrad_block_order(p, tile, split);
   const int tile_c = (int)(tile % (unsigned)p.ntiles_c);
   const int tile_k = (int)(tile / (unsigned)p.ntiles_c);
   const int k0 = tile_k * BMK, c0 = tile_c * BNC;
@@ -751,7 +770,8 @@ void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split) {
   if (!use_ring(bmk, bnc)) {
     // single-stage kernel (round 1): ~64 stages (4096 pixels) per workgroup, grid within [512, 2048] workgroups
     int s = (M + 4095) / 4096;
-    const int smin = (512 + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
+    static const int minwg = [] { const char* e = getenv("ICAMD_WGRAD_MINWG"); return e ? atoi(e) : 512; }();
+    const int smin = (minwg + tiles - 1) / tiles, smax = (2048 + tiles - 1) / tiles;
     if (s < smin) s = smin;
     if (s > smax) s = smax;
     const int cap = (M + BKR - 1) / BKR;
@@ -834,6 +854,9 @@ int icamd_wgrad_launch(WgradParams& p, hipStream_t stream) {
   p.divCin = make_fastdiv((unsigned)p.Cin);
   p.divKW = make_fastdiv((unsigned)p.KW);
   p.pointwise = (!p.stem7 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0) ? 1 : 0;
+  // ICAMD_WGRAD_XCD=0: the order of rounds 1-4 (A/B); both orders are bijections on any device
+  static const int xcd_chunk = [] { const char* e = getenv("ICAMD_WGRAD_XCD"); return (e ? atoi(e) : 1) && icamd_num_xccs() == 8; }();
+  p.xcd_chunk = xcd_chunk;
   if (!use_ring(bmk, bnc)) {
     if (bmk == 64) return bnc == 64 ? launch<64, 64>(p, stream) : launch<64, 128>(p, stream);
     return bnc == 64 ? launch<128, 64>(p, stream) : launch<128, 128>(p, stream);

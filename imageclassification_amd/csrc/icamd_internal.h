@@ -74,6 +74,7 @@ struct GemmNtParams {
   const bf16_t* gelu_z;  // optional [M][N]: out = rounded result * gelu'(gelu_z)
   int ntiles_n;          // filled by the launcher
   int group_n;           // 8-phase kernel: n-tiles per group of its tile order (filled by the launcher)
+  int out_policy;        // cache policy of the output stores: 0 plain, 1 sc1 (the line leaves the XCD's L2), 2 nt (filled by the launcher)
 };
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream);
 // true when the 256x256-tile kernel is expected to beat the 128x128 implicit-GEMM kernel for this problem
@@ -151,6 +152,7 @@ struct WgradParams {
   int S, rows_per_split;  // split of the m reduction
   int ntiles_k, ntiles_c;
   int pointwise;      // 1x1, stride 1, pad 0: the gather is the identity
+  int xcd_chunk;      // workgroup order: 1 = contiguous chunks of the split-major list per XCD (conv_wgrad.hip wgrad_block_order)
   int stem7;          // ResNet stem on the rgb4 layout: k = row*32 + pixel*4 + channel, IW = padded pitch, Cin = 4
   FastDiv divHW, divW, divCin, divKW;
 };

@@ -149,28 +149,45 @@ LARGE_POINTWISE = [
 ]
 
 
-def _memo(key, fn):
+def _memo(key, fn, *inputs):
     """CPU-oracle results of the large pointwise cases, shared between this process and the forced-route child processes that
-    re-run the same cases through other kernels (the oracle of LARGE_POINTWISE costs ~25 s per pass on the GPU box's host):
-    keyed by the case and the oracle source's mtime, stored under the system temp directory."""
+    re-run the same cases through other kernels (the oracle of LARGE_POINTWISE costs ~25 s per pass on the GPU box's host).
+    Keyed by the case, the BYTES of the oracle's input tensors, the oracle source's mtime and the torch version (a changed seed,
+    scale or torch build can never meet a stale tensor); stored in a directory of this user's own (mode 0700, owner checked --
+    a directory someone else planted is not used) and read back with weights_only=True (tensors only, no pickled code)."""
     import hashlib
+    import stat
     import tempfile
-    stamp = os.path.getmtime(R.__file__)
-    name = hashlib.sha1(repr((key, stamp)).encode()).hexdigest()[:20]
-    path = os.path.join(tempfile.gettempdir(), "icamd_oracle_memo_%d" % os.getuid(), name + ".pt")
-    if os.path.exists(path):
+    h = hashlib.sha1(repr((key, os.path.getmtime(R.__file__), torch.__version__)).encode())
+    for t in inputs:
+        if t is None:
+            h.update(b"none")
+        else:
+            tc = t.detach().contiguous().cpu()
+            h.update(repr((tuple(tc.shape), str(tc.dtype))).encode())
+            h.update(tc.view(torch.uint8).numpy().tobytes())
+    root = os.path.join(tempfile.gettempdir(), "icamd_oracle_memo_%d" % os.getuid())
+    path = os.path.join(root, h.hexdigest()[:24] + ".pt")
+    usable = False
+    try:
+        os.makedirs(root, mode=0o700, exist_ok=True)
+        st = os.lstat(root)
+        usable = stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0
+    except OSError:
+        pass
+    if usable and os.path.exists(path):
         try:
-            return torch.load(path)
+            return torch.load(path, weights_only=True)
         except Exception:
             pass
     val = fn()
-    try:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        tmp = path + ".%d.tmp" % os.getpid()
-        torch.save(val, tmp)
-        os.replace(tmp, path)
-    except OSError:
-        pass
+    if usable:
+        try:
+            tmp = path + ".%d.tmp" % os.getpid()
+            torch.save(val, tmp)
+            os.replace(tmp, path)
+        except OSError:
+            pass
     return val
 
 
@@ -186,7 +203,8 @@ def _run_large_pointwise(lib, cases):
         xd, wd = to_dev_bf16(x), to_dev_bf16(w)
         for use_extra in (False, True):
             ref = _memo(("pw_fwd", case, use_extra),
-                        lambda: R.conv2d_fwd(x, w, 1, 0, bias if use_extra else None, addend if use_extra else None))
+                        lambda: R.conv2d_fwd(x, w, 1, 0, bias if use_extra else None, addend if use_extra else None),
+                        x, w, bias if use_extra else None, addend if use_extra else None)
             y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
             bd = bias.to(DEV) if use_extra else None
             ad = to_dev_bf16(addend) if use_extra else None
@@ -206,7 +224,7 @@ def _run_large_pointwise(lib, cases):
                                     hip.stream_ptr()) == 0
         sync()
         got = y.float().cpu()
-        assert R.rel_l2(got, _memo(("pw_fwd", case, False), lambda: R.conv2d_fwd(x, w, 1, 0, None, None))) <= 1e-3
+        assert R.rel_l2(got, _memo(("pw_fwd", case, False), lambda: R.conv2d_fwd(x, w, 1, 0, None, None), x, w, None, None)) <= 1e-3
         s1, s2 = R.conv2d_stats(got)
         st = stats.double().cpu()
         assert torch.isfinite(st).all()
@@ -217,7 +235,8 @@ def _run_large_pointwise(lib, cases):
         w_t = w.permute(3, 1, 2, 0).contiguous()
         dyd, wtd = to_dev_bf16(dy), to_dev_bf16(w_t)
         for use_add in (False, True):
-            ref = _memo(("pw_dgrad", case, use_add), lambda: R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in if use_add else None))
+            ref = _memo(("pw_dgrad", case, use_add), lambda: R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in if use_add else None),
+                        dy, w, add_in if use_add else None)
             dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
             ad = to_dev_bf16(add_in) if use_add else None
             rc = lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), None,
@@ -231,7 +250,7 @@ def _run_large_pointwise(lib, cases):
         if Cin % 64 == 0:   # addend counted only where its ReLU-mask bit is set (residual shortcut)
             mask = torch.rand(N, H, W, Cin, generator=torch.Generator().manual_seed(17)) > 0.4
             bits = (mask.reshape(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8)
-            ref = _memo(("pw_dgrad_mask", case), lambda: R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in * mask))
+            ref = _memo(("pw_dgrad_mask", case), lambda: R.conv2d_dgrad(dy, w, (H, W), 1, 0, add_in * mask), dy, w, add_in, mask)
             dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
             ad, bd = to_dev_bf16(add_in), bits.to(DEV)
             assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyd), hip.ptr(wtd), hip.ptr(dx), hip.ptr(ad), hip.ptr(bd),
