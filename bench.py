@@ -130,8 +130,11 @@ CLASS_KERNELS = {
     "ln_fwd": ("layernorm_fwd_kernel",), "ln_bwd": ("layernorm_bwd_kernel",),
     "elementwise": ("layerscale_", "gelu_fwd_kernel", "gelu_bwd_kernel"),
     "dwconv": ("dwconv7_",),
+    # round 5: BatchNorm-backward apply + data gradient + weight gradient of a bottleneck's conv3 in one launch (its finalize and
+    # slab fold are launched by the same C-ABI call and counted in its time; they carry the bn_bwd_ / slab_reduce names)
+    "conv_bn_bwd_fused": ("conv1x1_bn_bwd_fused_kernel",),
 }
-MFMA_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "attn_fwd", "attn_bwd")
+MFMA_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "attn_fwd", "attn_bwd", "conv_bn_bwd_fused")
 
 
 def kernel_source_hash():
@@ -382,10 +385,10 @@ def main():
         # ---- HBM bytes from the committed rocprofv3 --pmc passes (profiles/): only used when the summary was collected for THIS
         # workload on THESE kernel sources (hash stamp), else null + a note
         pmc, traffic_note = None, None
-        default_pmc = {"resnet50": "r04_pmc_traffic.json", "vit_base_patch16_224": "r04_pmc_traffic_vit.json",
-                       "convnext_tiny": "r04_pmc_traffic_convnext.json"}.get(args.arch, "r04_pmc_traffic.json")
+        default_pmc = {"resnet50": "r05_pmc_traffic.json", "vit_base_patch16_224": "r05_pmc_traffic_vit.json",
+                       "convnext_tiny": "r05_pmc_traffic_convnext.json"}.get(args.arch, "r05_pmc_traffic.json")
         if is_eval:
-            default_pmc = "r04_pmc_traffic_eval.json"
+            default_pmc = "r05_pmc_traffic_eval.json"
         pmc_file = args.pmc_file or default_pmc
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))

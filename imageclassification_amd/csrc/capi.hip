@@ -28,6 +28,8 @@ int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, 
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,
                               const float* invstd, const float* scale, float* dgamma, float* dbeta, bf16_t* dy,
                               long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s, int sums_are_gy = 0);
+int icamd_bn_bwd_finalize_launch(const float* part, int nrows, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                 long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s, int sums_are_gy);
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s);
 int icamd_bn_relu_maxpool_fwd_launch(const bf16_t* y, const float* scale, const float* shift, bf16_t* out, unsigned char* idx,
@@ -100,7 +102,7 @@ int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base
 #include <vector>
 namespace {
 enum ProfClass { PC_IGEMM_FWD = 0, PC_IGEMM_DGRAD, PC_WGRAD, PC_BN_FINALIZE, PC_BN_APPLY, PC_BN_BWD, PC_POOL, PC_PACK,
-                 PC_LOSS, PC_OPTIM, PC_MISC, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_ELEMWISE, PC_DWCONV, PC_COUNT };
+                 PC_LOSS, PC_OPTIM, PC_MISC, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_ELEMWISE, PC_DWCONV, PC_FUSED_BWD, PC_COUNT };
 // Besides the elapsed time every call books its ALGORITHMIC work (round 4): bytes = each operand tensor of the call
 // read once and each result written once at the stored width (bf16 activations, fp32 parameters / gradients), two-pass
 // kernels counted as the two passes they are; flops = 2 x multiply-adds of the contraction.  bench.py divides by the time.
@@ -154,7 +156,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" {
 
-int icamd_abi_version(void) { return 4; }
+int icamd_abi_version(void) { return 5; }
 
 int icamd_prof_enable(int on) { g_prof_on = on != 0; return ICAMD_OK; }
 int icamd_prof_classes(void) { return PC_COUNT; }
@@ -704,6 +706,56 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
   ws += bn_chunk_bytes(C);
   return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
                                    (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream, 1);
+}
+
+// ---- fused backward of "pointwise convolution -> BatchNorm" (conv_fused_bwd.hip) -----------------------------------------
+int icamd_conv1x1_bn_bwd_fused_supported(const icamd_conv_desc* d) {
+  if (!conv_desc_ok(d) || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0) return 0;
+  return icamd_conv1x1_bn_bwd_fused_wanted((long long)d->N * d->OH * d->OW, d->Cin, d->Cout) ? 1 : 0;
+}
+
+size_t icamd_conv1x1_bn_bwd_fused_workspace_bytes(const icamd_conv_desc* d) {
+  if (!icamd_conv1x1_bn_bwd_fused_supported(d)) return 0;
+  int S = 1, rows = 0;
+  icamd_conv1x1_bn_bwd_fused_plan(d->N * d->OH * d->OW, d->Cin, &S, &rows);
+  return (size_t)S * d->Cout * d->Cin * sizeof(float);
+}
+
+int icamd_conv1x1_bn_bwd_fused(const icamd_conv_desc* d, const float* partials, int nrows, const void* g, const void* y,
+                               const float* mean, const float* invstd, const float* scale, float* dgamma, float* dbeta,
+                               const void* x, const void* w_t, void* dx, float* dw, int accumulate, void* bn_workspace,
+                               size_t bn_workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* stream) {
+  ProfScope _prof(PC_FUSED_BWD, stream);
+  if (d != nullptr) {
+    const ConvWork cw = conv_work(d);
+    _prof.work(2.0 * cw.out + 2.0 * cw.in + 4.0 * cw.w + 8.0 * nrows * d->Cout, 2.0 * cw.flops);   // g, y read; x read, dx written; dw
+  }
+  if (partials == nullptr || nrows <= 0 || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr ||
+      dgamma == nullptr || dbeta == nullptr || x == nullptr || w_t == nullptr || dx == nullptr || dw == nullptr ||
+      bn_workspace == nullptr || wgrad_workspace == nullptr)
+    return ICAMD_ERR_BAD_ARG;
+  if (!icamd_conv1x1_bn_bwd_fused_supported(d)) return ICAMD_ERR_UNSUPPORTED;
+  const int C = d->Cout;
+  if (bn_workspace_bytes < icamd_bn_bwd_apply_workspace_bytes(C) ||
+      wgrad_workspace_bytes < icamd_conv1x1_bn_bwd_fused_workspace_bytes(d))
+    return ICAMD_ERR_WORKSPACE;
+  const long long M = (long long)d->N * d->OH * d->OW;
+  char* ws = (char*)bn_workspace;
+  double* chunks = (double*)(ws + 256);
+  ws += bn_chunk_bytes(C);
+  float* c1c2 = (float*)ws;
+  int rc = icamd_bn_bwd_finalize_launch(partials, nrows, mean, invstd, dgamma, dbeta, M, C, accumulate, chunks, c1c2,
+                                        (hipStream_t)stream, 1);
+  if (rc) return rc;
+  FusedBwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.g = (const bf16_t*)g; p.y = (const bf16_t*)y; p.x = (const bf16_t*)x; p.wt = (const bf16_t*)w_t; p.dx = (bf16_t*)dx;
+  p.slab = (float*)wgrad_workspace;
+  p.mean = mean; p.invstd = invstd; p.scale = scale; p.c1 = c1c2; p.c2 = c1c2 + C;
+  p.M = (int)M; p.CI = d->Cin; p.CO = C;
+  rc = icamd_conv1x1_bn_bwd_fused_launch(p, (hipStream_t)stream);
+  if (rc) return rc;
+  return icamd_slab_reduce_launch(p.slab, dw, (long long)C * d->Cin, p.S, accumulate, (hipStream_t)stream);
 }
 
 // ---- LayerNorm / GELU / column sums (ViT, ConvNeXt) -------------------------------------------------------------

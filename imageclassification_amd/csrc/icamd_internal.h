@@ -140,6 +140,23 @@ int icamd_stem_wgrad_resident_splits(int N, int H);
 int icamd_stem_wgrad_resident_launch(StemWgradParams& p, int S, hipStream_t stream);
 int icamd_stem_resident_launch(StemParams& p, hipStream_t stream);
 
+// Fused backward of "pointwise convolution -> BatchNorm" (conv_fused_bwd.hip): BatchNorm-backward apply + data gradient + weight
+// gradient of the convolution in one pass over g and y
+struct FusedBwdParams {
+  const bf16_t* g;      // [M][CO] masked output gradient of the BatchNorm
+  const bf16_t* y;      // [M][CO] BatchNorm input (raw convolution output)
+  const bf16_t* x;      // [M][CI] convolution input
+  const bf16_t* wt;     // [CI][CO] transposed filter
+  bf16_t* dx;           // [M][CI]
+  float* slab;          // [S][CO][CI] partial filter gradients
+  const float *mean, *invstd, *scale, *c1, *c2;   // [CO]: batch statistics, gamma * invstd, mean g, mean g * xhat
+  int M, CI, CO;
+  int S, rows_per_split, nslices, xcd_pairs;      // filled by the launcher
+};
+bool icamd_conv1x1_bn_bwd_fused_wanted(long long M, int Cin, int Cout);
+void icamd_conv1x1_bn_bwd_fused_plan(int M, int Cin, int* S, int* rows_per_split);
+int icamd_conv1x1_bn_bwd_fused_launch(FusedBwdParams& p, hipStream_t stream);
+
 // Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
 struct WgradParams {
   const bf16_t* x;    // [N, IH, IW, Cin]

@@ -982,6 +982,20 @@ int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, 
   return icamd_launch_status();
 }
 
+// Finalize half of the BatchNorm backward alone: partial rows -> c1 = mean g, c2 = mean g * xhat (c1c2[0..C), [C..2C)) and the
+// gamma / beta gradients.  The apply half then runs wherever the caller wants it (conv_fused_bwd.hip: inside the convolution's
+// backward kernel).
+int icamd_bn_bwd_finalize_launch(const float* part, int nrows, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                 long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s, int sums_are_gy) {
+  int rpc, nc;
+  chunking(nrows, &rpc, &nc);
+  BnFinalizeArgs a = {};
+  a.dgamma = dgamma; a.dbeta = dbeta; a.c1_out = c1c2; a.c2_out = c1c2 + C; a.accumulate = accumulate; a.count = (double)rows;
+  if (sums_are_gy) { a.gy_mean = mean; a.gy_invstd = invstd; }
+  launch_reduce_finalize<1>(part, chunks, nrows, C, rpc, nc, a, s);
+  return icamd_launch_status();
+}
+
 // BN backward from pass-1 partials produced elsewhere (the fused data-gradient epilogue): finalize + apply pass.
 // g is already masked, so the apply kernel runs without a ReLU mask; shift is unused in that mode.
 int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, const bf16_t* y, const float* mean,

@@ -757,6 +757,7 @@ class ResNet(PicklableModel):
             mask = b["mask"].data_ptr()
             yk = next_y()
             y2 = None
+            fused_conv3 = False
             if "down_conv" in blk and _DUAL_BNBWD:
                 # the block's last BatchNorm and its shortcut's BatchNorm take the same masked gradient: one reduce and one
                 # apply pass for both (dout and the mask bits are read twice instead of four times)
@@ -774,16 +775,38 @@ class ResNet(PicklableModel):
                 bnl = bns[-1]
                 stl = self.stat_arena.data_ptr() + 4 * bnl.stat_offset
                 cl = bnl.c
-                hip.check(lib.icamd_bn_bwd_from_gy_partials(ws["bnb_part"].data_ptr(), fused_rows, dout, b["y"][-1].data_ptr(),
-                                                            stl, stl + 4 * cl, stl + 8 * cl, self._gf(bnl.weight),
-                                                            self._gf(bnl.bias), ypool[yk], b["y"][-1].numel() // cl, cl, acc,
-                                                            ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"], s),
-                          bnl.name + " bwd (apply, sums from the data gradient)")
+                d3 = convs[-1].desc(N, *hw_in[-1])
+                if self.block == "bottleneck" and lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(d3)):
+                    # conv3 + bn3 backward in one pass over g and y3 (round 5): BatchNorm finalize from the partial sums, dy3 only in
+                    # LDS, d(a2) -> DA and the filter gradient out of the same launch; main stream (its own slab workspace: the
+                    # side stream's weight gradients own ws["wgrad_ws"])
+                    fws = ws.get("fused_ws")
+                    need = lib.icamd_conv1x1_bn_bwd_fused_workspace_bytes(ctypes.byref(d3))
+                    if fws is None or fws.numel() < need:
+                        fws = ws["fused_ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                    hip.check(lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(d3), ws["bnb_part"].data_ptr(), fused_rows, dout,
+                                                             b["y"][-1].data_ptr(), stl, stl + 4 * cl, stl + 8 * cl,
+                                                             self._gf(bnl.weight), self._gf(bnl.bias), b["a"][nconv - 2].data_ptr(),
+                                                             self._wt(convs[-1]), DA, self._gf(convs[-1].w), acc,
+                                                             ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"], fws.data_ptr(),
+                                                             fws.numel(), s), bnl.name + " + " + convs[-1].name + " bwd (fused)")
+                    fused_conv3 = True
+                else:
+                    hip.check(lib.icamd_bn_bwd_from_gy_partials(ws["bnb_part"].data_ptr(), fused_rows, dout, b["y"][-1].data_ptr(),
+                                                                stl, stl + 4 * cl, stl + 8 * cl, self._gf(bnl.weight),
+                                                                self._gf(bnl.bias), ypool[yk], b["y"][-1].numel() // cl, cl, acc,
+                                                                ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"], s),
+                              bnl.name + " bwd (apply, sums from the data gradient)")
             else:
                 bn_bwd(bns[-1], dout, None, b["y"][-1], ypool[yk], None, True, mask)
             fused_rows = 0
             for i in range(nconv - 1, 0, -1):
                 x_i = b["a"][i - 1]
+                if fused_conv3 and i == nconv - 1:
+                    # conv3's data and weight gradients came out of the fused launch (DA, grad arena)
+                    yk = next_y()
+                    bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], ypool[yk], None, True)
+                    continue
                 # wgrad first: measured, it overlaps best with the data-gradient kernel of the same layer (issued after it,
                 # i.e. beside the next BatchNorm backward whose 1024 workgroups fill every wave slot, the gain disappears)
                 wgrad(convs[i], x_i.data_ptr(), ypool[yk], N, *hw_in[i], ybuf=yk)

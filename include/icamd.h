@@ -194,6 +194,22 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
                                   long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* Round 5: the whole backward of "1x1 convolution -> BatchNorm" at the end of a bottleneck block (timm Bottleneck.conv3 + bn3 under
+ * loss.backward(), /root/reference/engine.py:64,72) in ONE pass over the 4*planes-wide tensors:
+ *   c1, c2, dgamma, dbeta from the partial rows (sum g, sum g*y) an icamd_conv2d_dgrad_bnred call left (as icamd_bn_bwd_from_gy_partials),
+ *   dy = scale * (g - c1 - xhat * c2)  -- never stored --,  dx = dy * w  (bf16 [N,IH,IW,Cin]),  dw (+)= dy^T x  (fp32 [Cout][Cin]).
+ * d describes the convolution (1x1, stride 1, no padding); x is its input, w_t its transposed filter [Cin][Cout]; g, y are
+ * [N,OH,OW,Cout] (g already masked by the block's ReLU bits).  bn_workspace as icamd_bn_bwd_from_gy_partials
+ * (icamd_bn_bwd_apply_workspace_bytes(Cout), zero-filled once); wgrad_workspace >= icamd_conv1x1_bn_bwd_fused_workspace_bytes(d).
+ * _supported: 1 for (Cin, Cout) = (64, 256) and (128, 512) with >= 16384 pixels; elsewhere the caller keeps
+ * icamd_bn_bwd_from_gy_partials + icamd_conv2d_dgrad + icamd_conv2d_wgrad, which compute the same three results. */
+int icamd_conv1x1_bn_bwd_fused_supported(const icamd_conv_desc* d);
+size_t icamd_conv1x1_bn_bwd_fused_workspace_bytes(const icamd_conv_desc* d);
+int icamd_conv1x1_bn_bwd_fused(const icamd_conv_desc* d, const float* partials, int nrows, const void* g, const void* y,
+                               const float* mean, const float* invstd, const float* scale, float* dgamma, float* dbeta,
+                               const void* x, const void* w_t, void* dx, float* dw, int accumulate, void* bn_workspace,
+                               size_t bn_workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* stream);
+
 /* ---- LayerNorm / GELU / long column sums (ViT and ConvNeXt layers of the same reference calls; LayerNorm spec
  *      /root/reference/semantic_segmentation/backbone/convnext.py:158-182, exact-erf GELU :37) ------------------- */
 /* y = (x - mean_C) * rstd * gamma + beta over the last dimension of x [rows][C] (C % 4 == 0, C <= 1024);

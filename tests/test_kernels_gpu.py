@@ -1253,6 +1253,99 @@ def test_conv_dgrad_addend_maskbits(lib):
                                   hip.stream_ptr()) == 1      # bits without an addend: bad argument
 
 
+@pytest.mark.parametrize("case", [(8, 48, 48, 64, 256), (3, 75, 75, 64, 256), (8, 48, 48, 128, 512), (3, 75, 75, 128, 512)])
+def test_conv1x1_bn_bwd_fused(lib, case):
+    """icamd_conv1x1_bn_bwd_fused (round 5): the backward of a bottleneck's conv3 + bn3 in one pass -- BatchNorm-backward finalize
+    from (sum g, sum g*y) partial rows, dy = scale * (g - c1 - xhat * c2) kept in LDS, dx = dy * w, dw = dy^T x -- against the
+    oracle's three steps (R.bn_bwd, R.conv2d_dgrad, R.conv2d_wgrad), against the three-launch device path it replaces
+    (icamd_bn_bwd_from_gy_partials + icamd_conv2d_dgrad + icamd_conv2d_wgrad: same dy bit for bit, so dx may differ by the fp32
+    accumulation order only), twice for bit-reproducibility, with accumulate, and with a ragged last tile (M % 32 != 0)."""
+    hip = _hip()
+    N, H, W, Cin, Cout = case
+    d = hip.conv_desc(N, H, W, Cin, Cout, 1, 1, 1, 0)
+    assert lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(d)) == 1
+    M = N * H * W
+    gen = torch.Generator().manual_seed(150)
+    gmask = torch.rand(N, H, W, Cout, generator=gen) > 0.45
+    g = rnd_bf16(N, H, W, Cout, seed=151) * gmask                          # masked output gradient of the BatchNorm
+    y = R.bf16_round(rnd_bf16(N, H, W, Cout, scale=1.5, seed=152) + 0.3)   # its input, deliberately not zero-mean
+    x = rnd_bf16(N, H, W, Cin, seed=153).clamp_min(0)                      # conv3's input (a post-ReLU activation)
+    w = rnd_bf16(Cout, 1, 1, Cin, scale=(1.0 / Cin) ** 0.5, seed=154)
+    yy = y.double().reshape(-1, Cout)
+    mean, var = yy.mean(0), yy.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma = 0.5 + torch.rand(Cout, generator=gen)
+    scale = gamma * invstd.float()
+    # oracle
+    rdy, rdgamma, rdbeta, _ = R.bn_bwd(g, torch.ones_like(g), y, mean.float(), invstd.float(), scale)
+    rdx = R.conv2d_dgrad(rdy, w, (H, W), 1, 0, None)
+    rdw = R.conv2d_wgrad(x, rdy, (1, 1), 1, 0)
+    # partial rows as icamd_conv2d_dgrad_bnred leaves them: [ceil(M/128)][2][Cout] = (sum g, sum g*y) per 128 rows
+    rows = (M + 127) // 128
+    g2, y2 = g.double().reshape(-1, Cout), y.double().reshape(-1, Cout)
+    pad = rows * 128 - M
+    g2p = torch.cat([g2, torch.zeros(pad, Cout, dtype=torch.float64)]).reshape(rows, 128, Cout)
+    y2p = torch.cat([y2, torch.zeros(pad, Cout, dtype=torch.float64)]).reshape(rows, 128, Cout)
+    part = torch.stack([g2p.sum(1), (g2p * y2p).sum(1)], 1).float().to(DEV).contiguous()
+    gd, yd, xd = to_dev_bf16(g), to_dev_bf16(y), to_dev_bf16(x)
+    wtd = to_dev_bf16(w.permute(3, 1, 2, 0).contiguous())
+    md, isd, scd = mean.float().to(DEV), invstd.float().to(DEV), scale.to(DEV)
+    s = hip.stream_ptr()
+    bwsb = lib.icamd_bn_bwd_apply_workspace_bytes(Cout)
+    bws = torch.zeros(bwsb, dtype=torch.uint8, device=DEV)
+    wsb = lib.icamd_conv1x1_bn_bwd_fused_workspace_bytes(ctypes.byref(d))
+    assert wsb > 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+
+    def fused(acc, dw, dgam, dbet):
+        dx = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+        rc = lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(d), hip.ptr(part), rows, hip.ptr(gd), hip.ptr(yd), hip.ptr(md), hip.ptr(isd),
+                                            hip.ptr(scd), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(xd), hip.ptr(wtd), hip.ptr(dx),
+                                            hip.ptr(dw), acc, hip.ptr(bws), bwsb, hip.ptr(ws), wsb, s)
+        assert rc == 0
+        sync()
+        return dx
+
+    dw = torch.full((Cout, Cin), float("nan"), device=DEV)
+    dgam, dbet = torch.full((Cout,), float("nan"), device=DEV), torch.full((Cout,), float("nan"), device=DEV)
+    dx = fused(0, dw, dgam, dbet)
+    got = dx.float().cpu()
+    assert torch.isfinite(got).all() and R.rel_l2(got, rdx) <= 1e-3 and R.bf16_close(got, rdx)
+    gw = dw.cpu().reshape(Cout, 1, 1, Cin)
+    assert torch.isfinite(gw).all() and R.rel_l2(gw, rdw) <= 1e-3
+    assert R.rel_l2(dgam.cpu(), rdgamma) <= 1e-4 and R.rel_l2(dbet.cpu(), rdbeta) <= 1e-4
+    # bit-reproducible
+    dw2 = torch.empty_like(dw)
+    dg2, db2 = torch.empty_like(dgam), torch.empty_like(dbet)
+    dx2 = fused(0, dw2, dg2, db2)
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(dg2, dgam) and torch.equal(db2, dbet)
+    # accumulate: the filter and BatchNorm gradients add onto what is there; dx is overwritten
+    fused(1, dw2, dg2, db2)
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-6, atol=0) and torch.allclose(dg2, 2 * dgam, rtol=1e-6, atol=0)
+    # the three launches it replaces: same dy bit for bit => dx within the fp32 accumulation order, dw to fp32 noise
+    dyo = torch.empty_like(gd)
+    dgam3, dbet3 = torch.zeros(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+    assert lib.icamd_bn_bwd_from_gy_partials(hip.ptr(part), rows, hip.ptr(gd), hip.ptr(yd), hip.ptr(md), hip.ptr(isd), hip.ptr(scd),
+                                             hip.ptr(dgam3), hip.ptr(dbet3), hip.ptr(dyo), M, Cout, 0, hip.ptr(bws), bwsb, s) == 0
+    dx3 = torch.empty_like(dx)
+    assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dyo), hip.ptr(wtd), hip.ptr(dx3), None, None, s) == 0
+    w3b = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    w3 = torch.empty(w3b, dtype=torch.uint8, device=DEV)
+    dw3 = torch.empty_like(dw)
+    assert lib.icamd_conv2d_wgrad(ctypes.byref(d), hip.ptr(xd), hip.ptr(dyo), hip.ptr(dw3), 0, hip.ptr(w3), w3b, s) == 0
+    sync()
+    assert torch.equal(dgam3, dgam) and torch.equal(dbet3, dbet)
+    assert R.max_bf16_ulp(dx.float().cpu(), dx3.float().cpu()) <= 1.0
+    assert float((dx != dx3).float().mean()) <= 2e-2
+    assert R.rel_l2(dw.cpu(), dw3.cpu()) <= 1e-5
+    # shapes without this form are refused (the caller keeps the three launches)
+    d2 = hip.conv_desc(2, 14, 14, 256, 1024, 1, 1, 1, 0)
+    assert lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(d2)) == 0
+    assert lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(d2), hip.ptr(part), rows, hip.ptr(gd), hip.ptr(yd), hip.ptr(md), hip.ptr(isd),
+                                          hip.ptr(scd), hip.ptr(dgam), hip.ptr(dbet), hip.ptr(xd), hip.ptr(wtd), hip.ptr(dx),
+                                          hip.ptr(dw), 0, hip.ptr(bws), bwsb, hip.ptr(ws), wsb, s) == 2
+
+
 @pytest.mark.parametrize("case", [(4, 48, 48, 256, 64), (3, 56, 56, 512, 128), (12, 28, 28, 1024, 256), (5, 41, 41, 256, 64)])
 def test_conv_dgrad_bnred(lib, case):
     """icamd_conv2d_dgrad_bnred: the residual data gradient of a bottleneck's conv1 (Cin = 4 * planes <- Cout = planes) whose
