@@ -1321,7 +1321,8 @@ def test_conv1x1_bn_bwd_fused(lib, case):
     assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(dg2, dgam) and torch.equal(db2, dbet)
     # accumulate: the filter and BatchNorm gradients add onto what is there; dx is overwritten
     fused(1, dw2, dg2, db2)
-    assert torch.allclose(dw2, 2 * dw, rtol=1e-6, atol=0) and torch.allclose(dg2, 2 * dgam, rtol=1e-6, atol=0)
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-5, atol=1e-5 * float(dw.abs().max()))
+    assert torch.allclose(dg2, 2 * dgam, rtol=1e-5, atol=1e-5 * float(dgam.abs().max()))
     # the three launches it replaces: same dy bit for bit => dx within the fp32 accumulation order, dw to fp32 noise
     dyo = torch.empty_like(gd)
     dgam3, dbet3 = torch.zeros(Cout, device=DEV), torch.zeros(Cout, device=DEV)
