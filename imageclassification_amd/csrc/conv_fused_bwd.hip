@@ -31,6 +31,12 @@
 #include "icamd_internal.h"
 #include <cstdlib>
 
+// Measurement builds only (tools/fused_ablate/): bit 0 = no BatchNorm arithmetic (dy = g), bit 1 = no data-gradient MFMAs, bit 2 = no
+// weight-gradient MFMAs, bit 3 = no transform at all.  The product is always built with 0; results of the others are garbage.
+#ifndef ICAMD_FUSED_ABLATE
+#define ICAMD_FUSED_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int FTM = 32;          // rows per tile = one 32-deep MFMA step of the weight gradient
@@ -78,22 +84,31 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   }
 }
 
-template <int CO, int NBUF>
+template <int CO>
 __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const FusedBwdParams p) {
-  constexpr int ROWB = CO * 2;                    // bytes per g / y / dy row
-  constexpr int G_BYTES = FTM * ROWB;             // one g (or y) tile
+  // A UNIT = 32 rows x 256 output channels of g and y (+ the rows' 64 input channels of x): CO = 256 has one unit per row tile,
+  // CO = 512 two (h = 0, 1), staged, transformed and multiplied one after the other through the same ring of four 36 KB buffers --
+  // three units (108 KB) in flight per CU for both widths.  (Round 5, first form of CO = 512: whole 32 x 512 tiles, two 68 KB buffers,
+  // one tile in flight: 171 us for 0.51 GB = 3.0 TB/s, with the transform and the MFMA phase -- 35-40 us each by ablation,
+  // tools/fused_ablate/ -- exposed behind the loads.)
+  constexpr int NH = CO / 256;                    // units per row tile
+  constexpr int NBUF = 4;
+  constexpr int ROWB = 512;                       // bytes per staged g / y / dy row (256 channels)
+  constexpr int G_BYTES = FTM * ROWB;             // 16 KB
   constexpr int X_BYTES = FTM * FCI * 2;          // 4 KB
   constexpr int BUF_BYTES = 2 * G_BYTES + X_BYTES;
   constexpr int PATCH_BYTES = FTM * FCI * 2;      // dx tile [32][64] bf16
+  constexpr int NPATCH = NH == 1 ? 2 : 1;         // one unit per tile: the patch of tile t is stored while tile t + 1's is written
   constexpr int PATCH0 = NBUF * BUF_BYTES;
-  constexpr int CPR = CO / 8;                     // 16 B chunks per row
-  constexpr int GI = G_BYTES / 1024 / 8;          // LDS-DMA instructions per wave for one g (or y) tile: 2 or 4
-  constexpr int KS = CO / 32;                     // k-steps of the data gradient
-  constexpr int CR = CO / 4 / 16;                 // 16-channel fragments of dy per weight-gradient wave
-  constexpr int NV = FTM * CPR / 512;             // dy vectors per thread and tile
-  constexpr int RSTEP = 512 / CPR;                // rows between a thread's vectors
-  constexpr int CONST0 = PATCH0 + 2 * PATCH_BYTES;   // [5][CO] floats: mean, invstd, scale, c1, c2
-  constexpr int CONST_BYTES = 5 * CO * 4;
+  constexpr int CPR = 32;                         // 16 B chunks per staged row
+  constexpr int KSU = 8;                          // k-steps of the data gradient per unit
+  constexpr int KS = CO / 32;                     // ... per row tile
+  constexpr int CR = 4;                           // 16-channel fragments of dy per weight-gradient wave and unit
+  // The lane's BatchNorm constants (8 channels per unit).  CO = 256: 40 VGPRs of a 176-register kernel.  CO = 512: an LDS table read
+  // back per unit -- beside the 128 VGPRs of the resident filter / the accumulators the kernel spilled with them in registers.
+  constexpr bool CREG = CO == 256;
+  constexpr int CONST0 = PATCH0 + NPATCH * PATCH_BYTES;   // [5][CO] floats: mean, invstd, scale, c1, c2
+  constexpr int CONST_BYTES = CREG ? 0 : 5 * CO * 4;
   static_assert(CONST0 + CONST_BYTES <= 160 * 1024, "LDS");
   static_assert(CO == 256 || CO == 512, "instantiated widths");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[CONST0 + CONST_BYTES];
@@ -114,17 +129,21 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
   const int m_begin = split * p.rows_per_split;
   const int m_end = (p.M < m_begin + p.rows_per_split) ? p.M : m_begin + p.rows_per_split;
   const int ntiles = (m_end - m_begin + FTM - 1) / FTM;
+  const int nunits = ntiles * NH;
   const bf16_t* zero = (const bf16_t*)icamd_zero_page;
 
-  // ---- staging: instruction q = j * 8 + wave of a g / y tile covers LDS bytes [q * 1024, + 1024); the lane's row and source chunk are
-  // recomputed per call (a handful of VALU operations per 1 KiB instruction) rather than held in registers across the loop
-  auto stage = [&](int t, int buf) {
+  // ---- staging of unit u = tile * NH + h: instruction q = j * 8 + wave of the g / y part covers LDS bytes [q * 1024, + 1024) = two
+  // rows; the lane's row and source chunk are recomputed per call (a handful of VALU operations per 1 KiB instruction) rather than
+  // held in registers across the loop.  x travels with EVERY unit of its tile (the buffer of unit h = 0 is refilled while h = 1
+  // runs; the second read of the 4 KB comes from L2).
+  auto stage = [&](int u, int buf) {
+    const int t = u / NH, h = u - t * NH;
     const int m0 = m_begin + t * FTM;
     unsigned char* base = smem + buf * BUF_BYTES;
-    const bf16_t* gp = p.g + (long long)m0 * CO;
-    const bf16_t* yp = p.y + (long long)m0 * CO;
+    const bf16_t* gp = p.g + (long long)m0 * CO + h * 256;
+    const bf16_t* yp = p.y + (long long)m0 * CO + h * 256;
 #pragma unroll
-    for (int j = 0; j < GI; ++j) {
+    for (int j = 0; j < 2; ++j) {
       const int byte = (j * 8 + wave) * 1024 + lane * 16;
       const int row = byte / ROWB, pc = (byte % ROWB) >> 4;
       const int off = row * CO + ((pc ^ (dy_key(row) << 1)) << 3);
@@ -140,49 +159,50 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
       __builtin_amdgcn_global_load_lds(GPTR(ok ? p.x + (long long)m0 * p.CI + off : zero), LPTR(base + 2 * G_BYTES + wave * 1024), 16, 0, 0);
     }
   };
-  // prologue: the first NBUF - 1 tiles in flight under the constant / filter loads
+
+  // prologue: the first NBUF - 1 units in flight under the constant / filter loads
 #pragma unroll
   for (int k = 0; k < NBUF - 1; ++k)
-    if (k < ntiles) stage(k, k);
+    if (k < nunits) stage(k, k);
 
-  // ---- BatchNorm constants [5][CO] into LDS (read back per tile by the transform: held in registers across the loop they cost 40
-  // VGPRs beside the 128 of the resident filter / the accumulators at CO = 512 and the kernel spilled)
-  const int lc = tid % CPR, rbase = tid / CPR;
-  for (int idx = tid; idx < 5 * CO / 4; idx += 512) {
+  // ---- BatchNorm constants [5][CO] into LDS (CO = 512)
+  const int lc = tid % CPR, rbase = tid / CPR;   // this thread transforms chunk lc of rows rbase and rbase + 16
+  for (int idx = tid; !CREG && idx < 5 * CO / 4; idx += 512) {
     const int arr = idx / (CO / 4), c4 = idx - arr * (CO / 4);
     const float* src = arr == 0 ? p.mean : arr == 1 ? p.invstd : arr == 2 ? p.scale : arr == 3 ? p.c1 : p.c2;
     const f32x4 v = *(const f32x4*)(src + c4 * 4);
-    lds_store16(lds_base + (unsigned)(CONST0 + (arr * CO + c4 * 4) * 4), __builtin_bit_cast(u32x4, v));
+    // table layout [array][channel half hh of the 8-channel chunk][chunk]: the 16 B a lane reads sit next to its neighbours' (the
+    // first layout, [array][channel], had the lanes 32 B apart: two-way bank conflicts on 10 of the transform's 16 LDS instructions)
+    lds_store16(lds_base + (unsigned)(CONST0 + ((arr * 2 + (c4 & 1)) * (CO / 8) + (c4 >> 1)) * 16), __builtin_bit_cast(u32x4, v));
   }
-  const unsigned caddr = lds_base + (unsigned)(CONST0 + lc * 32);
+  const unsigned caddr = lds_base + (unsigned)(CONST0 + lc * 16);
 
-  // the constants are in flight to LDS, the prologue's staging loads to their buffers: everything of this wave has arrived (so the
+  // the constants are on their way to LDS, the prologue's staging loads to their buffers: everything of this wave has arrived (so the
   // counted waits of the loop may only over-wait, never under-wait); the first barrier of the loop publishes the constant table
   __builtin_amdgcn_s_waitcnt(0x0F70);
 
   // deferred row store of the dx tile of tile t (waves 0-3): 8 rows x 128 B per wave
   auto store_dx = [&](int t) {
     const int row = 8 * wave + (lane >> 3), c = lane & 7;
-    const unsigned a = lds_base + (unsigned)(PATCH0 + (t & 1) * PATCH_BYTES + row * 128 + ((c ^ (row & 7)) << 4));
+    const unsigned a = lds_base + (unsigned)(PATCH0 + (NPATCH == 2 ? (t & 1) : 0) * PATCH_BYTES + row * 128 + ((c ^ (row & 7)) << 4));
     u32x4 v = lds_load16(a);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
     const int m = m_begin + t * FTM + row;
     if (m < m_end) *(u32x4*)(p.dx + (long long)m * p.CI + ci0 + c * 8) = v;
   };
 
-  // ---- the tile loop, once per ROLE (wave-uniform branch around the whole loop, not inside it: with one loop and the roles'
+  // ---- the unit loop, once per ROLE (wave-uniform branch around the whole loop, not inside it: with one loop and the roles'
   // register sets overlaid the compiler kept two copies of the overlay, 2 x 128 VGPRs at CO = 512).  Both instances execute the
   // same barriers.  DG = data gradient (waves 0-3), else weight gradient (waves 4-7).
   auto run = [&](auto role) {
     constexpr bool DG = decltype(role)::value;
-    constexpr int L = 2 * GI + (DG ? 1 : 0);      // LDS-DMA instructions of this wave per tile
-    constexpr int S = DG ? 1 : 0;                 // deferred row stores of this wave per tile
+    constexpr int L = 4 + (DG ? 1 : 0);           // LDS-DMA instructions of this wave per unit
     // data gradient: wr = row half, wc = channel half; filter fragment (ks, j) = rows ci0 + 32 wc + 16 j + fr of w_t, all of CO
     const int wr = wave & 1, wc = (wave >> 1) & 1;
     bf16x8 wf[DG ? KS : 1][2];
-    // weight gradient: wq = quarter of the output channels; [64 input channels][CO / 4 output channels] of the filter gradient
+    // weight gradient: wq = quarter of each unit's 256 output channels; [64 input channels][64 output channels] per unit
     const int wq = wave & 3;
-    f32x4 wacc[DG ? 1 : 4][CR];
+    f32x4 wacc[DG ? 1 : NH][4][CR];
     // addresses inside a buffer.  Data gradient: ad[v] = row read of the k-steps with ks & 3 == v.  Weight gradient: ad[0] / ad[1] = x
     // reads of rows r0 / r1, ad[2] / ad[3] = dy reads, each for fragment 0 with the row's swizzle key in the (otherwise zero) 32 B-block
     // bits: fragment f is address ^ (f << 5) -- one v_xor per read instead of an address register per fragment
@@ -197,61 +217,70 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
       const int kx = dy_key(row) << 1;
 #pragma unroll
       for (int v = 0; v < 4; ++v) ad[v] = (unsigned)(row * ROWB + (((fq ^ (kx & 3)) | (((v ^ (kx >> 2)) & 3) << 2)) << 4));
-      __builtin_amdgcn_s_waitcnt(0x0F70);        // the filter
     } else {
       const int g4 = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
       const int r0 = 8 * g4 + q, r1 = r0 + 4;
-      // x rows are 128 B (bits 5-6 = block); dy rows >= 512 B with this wave's CR blocks at wq * CR (bits 5 .. 5 + log2 CR - 1 free)
+      // x rows are 128 B (bits 5-6 = block); dy rows 512 B with this wave's four blocks at 4 wq (bits 5-6 free)
       ad[0] = (unsigned)(2 * G_BYTES + r0 * 128 + (x_key(r0) << 5) + 8 * pq);
       ad[1] = (unsigned)(2 * G_BYTES + r1 * 128 + (x_key(r1) << 5) + 8 * pq);
       ad[2] = (unsigned)(r0 * ROWB + (((wq * CR) ^ dy_key(r0)) << 5) + 8 * pq);
       ad[3] = (unsigned)(r1 * ROWB + (((wq * CR) ^ dy_key(r1)) << 5) + 8 * pq);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int j = 0; j < CR; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < CR; ++j) wacc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
-    int buf = 0;
-    for (int t = 0; t < ntiles; ++t) {
-      // ---- this wave's loads of tile t have landed: younger in its queue are the loads of the tiles after t and the row stores
-      // issued since (one per iteration since the loads of tile t were issued, none before iteration 1)
-      {
-        const int nl = (ntiles - 1 - t < NBUF - 2) ? ntiles - 1 - t : NBUF - 2;
-        const int ns = (t - 1 < NBUF - 1) ? (t - 1 < 0 ? 0 : t - 1) : NBUF - 1;
-        wait_vmcnt_dyn(nl * L + ns * S);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();      // B1: tile t is complete for every wave; every wave is done with tile t - 1 (buffer and patch)
-      if (t + NBUF - 1 < ntiles) stage(t + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
-      if constexpr (DG) {
-        if (t > 0) store_dx(t - 1);
-      }
-      const unsigned bb = lds_base + (unsigned)(buf * BUF_BYTES);
-
-      // ---- (g, y) -> dy in place of g, two vectors of 8 channels at a time.  The lane's constants (its 8 channels never change)
-      // come from the LDS table in two halves of four channels through the same 20 registers.
+    f32x4 creg[CREG ? 5 : 1][2];
+    if constexpr (CREG) {
 #pragma unroll
-      for (int i0 = 0; i0 < NV; i0 += 2) {
+      for (int hh = 0; hh < 2; ++hh) {
+        creg[0][hh] = *(const f32x4*)(p.mean + lc * 8 + hh * 4);
+        creg[1][hh] = *(const f32x4*)(p.invstd + lc * 8 + hh * 4);
+        creg[2][hh] = *(const f32x4*)(p.scale + lc * 8 + hh * 4);
+        creg[3][hh] = *(const f32x4*)(p.c1 + lc * 8 + hh * 4);
+        creg[4][hh] = *(const f32x4*)(p.c2 + lc * 8 + hh * 4);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // the filter / the constants
+
+    f32x4 dacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+    // (g, y) -> dy in place of g for the unit in buffer `tb` (h = its half of CO): chunk lc of rows rbase and rbase + 16.  CO = 512:
+    // the lane's constants come from the LDS table in two halves of four channels through the same 20 registers.
+    auto transform = [&](auto hc, int tb) {
+      constexpr int h = decltype(hc)::value;
+      if constexpr ((ICAMD_FUSED_ABLATE & 8) == 0) {
+        const unsigned bb = lds_base + (unsigned)(tb * BUF_BYTES);
         u32x4 gv[2], yv[2], ov[2];
         unsigned addr[2];
         f32x4 cq[5];
+        if constexpr (!CREG) {
 #pragma unroll
-        for (int a = 0; a < 5; ++a) cq[a] = __builtin_bit_cast(f32x4, lds_load16(caddr + (unsigned)(a * CO * 4)));
+          for (int a = 0; a < 5; ++a) cq[a] = __builtin_bit_cast(f32x4, lds_load16(caddr + (unsigned)(((a * 2 + 0) * (CO / 8) + h * 32) * 16)));
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int row = rbase + RSTEP * (i0 + i);
+          const int row = rbase + 16 * i;
           addr[i] = bb + (unsigned)(row * ROWB + ((lc ^ (dy_key(row) << 1)) << 4));
           gv[i] = lds_load16(addr[i]);
           yv[i] = lds_load16(addr[i] + G_BYTES);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(yv[0]), "+v"(gv[1]), "+v"(yv[1]), "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]),
-                     "+v"(cq[3]), "+v"(cq[4])::"memory");
+        if constexpr (CREG) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(yv[0]), "+v"(gv[1]), "+v"(yv[1])::"memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gv[0]), "+v"(yv[0]), "+v"(gv[1]), "+v"(yv[1]), "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]),
+                       "+v"(cq[3]), "+v"(cq[4])::"memory");
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          if (hh == 1) {
+          if constexpr (CREG) {
 #pragma unroll
-            for (int a = 0; a < 5; ++a) cq[a] = __builtin_bit_cast(f32x4, lds_load16(caddr + (unsigned)(a * CO * 4 + 16)));
+            for (int a = 0; a < 5; ++a) cq[a] = creg[a][hh];
+          } else if (hh == 1) {
+#pragma unroll
+            for (int a = 0; a < 5; ++a) cq[a] = __builtin_bit_cast(f32x4, lds_load16(caddr + (unsigned)(((a * 2 + 1) * (CO / 8) + h * 32) * 16)));
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(cq[4])::"memory");
           }
 #pragma unroll
@@ -262,7 +291,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
               const unsigned gw = gv[i][hh * 2 + (e >> 1)], yw = yv[i][hh * 2 + (e >> 1)];
               const float g = (e & 1) ? bf16_hi(gw) : bf16_lo(gw);
               const float yy = (e & 1) ? bf16_hi(yw) : bf16_lo(yw);
-              o[e] = cq[2][e] * (g - cq[3][e] - ((yy - cq[0][e]) * cq[1][e]) * cq[4][e]);     // bn_bwd_apply_kernel's expression
+              if constexpr (ICAMD_FUSED_ABLATE & 1) o[e] = g + yy;
+              else o[e] = cq[2][e] * (g - cq[3][e] - ((yy - cq[0][e]) * cq[1][e]) * cq[4][e]);     // bn_bwd_apply_kernel's expression
             }
             ov[i][hh * 2] = pack_bf16x2(o[0], o[1]);
             ov[i][hh * 2 + 1] = pack_bf16x2(o[2], o[3]);
@@ -271,58 +301,106 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
         lds_store16(addr[0], ov[0]);
         lds_store16(addr[1], ov[1]);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();      // B2: dy of tile t is complete
+    };
 
+    // the role's MFMAs on the dy of unit (t, h) in buffer `mb`
+    auto multiply = [&](auto hc, int t, int mb) {
+      constexpr int h = decltype(hc)::value;
+      const unsigned bb = lds_base + (unsigned)(mb * BUF_BYTES);
       if constexpr (DG) {
-        // ---- data gradient: [16 rows][32 channels] per wave, K = CO, four row fragments of dy in flight
-        f32x4 dacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        static_for<0, KS / 4>([&](auto hc) {
-          constexpr int h = decltype(hc)::value;
+        // ---- data gradient: [16 rows][32 channels] per wave, this unit's 256 of the CO reduction channels, four row fragments of
+        // dy in flight
+        if constexpr (h == 0) { dacc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        static_for<0, (ICAMD_FUSED_ABLATE & 2) ? 0 : KSU / 4>([&](auto gc) {
+          constexpr int g0 = decltype(gc)::value * 4;
           bf16x8 a[4];
           static_for<0, 4>([&](auto kc) {
-            constexpr int ks = h * 4 + decltype(kc)::value;
+            constexpr int ks = g0 + decltype(kc)::value;
             a[ks & 3] = lds_read128_off<(ks >> 2) * 256>(bb + ad[ks & 3]);
           });
           static_for<0, 4>([&](auto kc) {
-            constexpr int k = decltype(kc)::value, ks = h * 4 + k;
+            constexpr int k = decltype(kc)::value, ks = g0 + k;
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[k]) : "n"(3 - k) : "memory");
 #pragma unroll
-            for (int j = 0; j < 2; ++j) dacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], a[k], dacc[j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) dacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h * KSU + ks][j], a[k], dacc[j], 0, 0, 0);
           });
         });
-        // lane: channels 32 wc + 16 j + 4 fq .. + 3 of row 16 wr + fr -> 8 B slot (8 wc + 4 j + fq) of the row in the patch
-        const int row = 16 * wr + fr;
-        const unsigned pa = lds_base + (unsigned)(PATCH0 + (t & 1) * PATCH_BYTES + row * 128);
+        if constexpr (h == NH - 1) {
+          // lane: channels 32 wc + 16 j + 4 fq .. + 3 of row 16 wr + fr -> 8 B slot (8 wc + 4 j + fq) of the row in the patch
+          const int row = 16 * wr + fr;
+          const unsigned pa = lds_base + (unsigned)(PATCH0 + (NPATCH == 2 ? (t & 1) : 0) * PATCH_BYTES + row * 128);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int slot = 8 * wc + 4 * j + fq;
-          u32x2 pk;
-          pk[0] = pack_bf16x2(dacc[j][0], dacc[j][1]);
-          pk[1] = pack_bf16x2(dacc[j][2], dacc[j][3]);
-          lds_store8(pa + (unsigned)((((slot >> 1) ^ (row & 7)) << 4) + ((slot & 1) << 3)), pk);
+          for (int j = 0; j < 2; ++j) {
+            const int slot = 8 * wc + 4 * j + fq;
+            u32x2 pk;
+            pk[0] = pack_bf16x2(dacc[j][0], dacc[j][1]);
+            pk[1] = pack_bf16x2(dacc[j][2], dacc[j][3]);
+            lds_store8(pa + (unsigned)((((slot >> 1) ^ (row & 7)) << 4) + ((slot & 1) << 3)), pk);
+          }
         }
       } else {
-        // ---- weight gradient, one 32-row step: x fragments once, dy fragments four at a time (CR = 8: two groups)
-        bf16x8 xf[4];
+        // ---- weight gradient, one 32-row step: [64 input channels][64 output channels of this unit] per wave
+        bf16x8 xf[4], yf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) xf[i] = tr_pair(bb + (ad[0] ^ (unsigned)(i << 5)), bb + (ad[1] ^ (unsigned)(i << 5)));
-        static_for<0, CR / 4>([&](auto jc) {
-          constexpr int j0 = decltype(jc)::value * 4;
-          bf16x8 yf[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) yf[j] = tr_pair(bb + (ad[2] ^ (unsigned)((j0 + j) << 5)), bb + (ad[3] ^ (unsigned)((j0 + j) << 5)));
-          static_for<0, 4>([&](auto jj) {
-            constexpr int j = decltype(jj)::value;
-            // reads return in issue order: dy fragment j is complete once at most 2 * (3 - j) reads are outstanding (the x fragments
-            // were issued before the first group)
-            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(yf[j]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]) : "n"(2 * (3 - j)) : "memory");
+        for (int j = 0; j < 4; ++j) yf[j] = tr_pair(bb + (ad[2] ^ (unsigned)(j << 5)), bb + (ad[3] ^ (unsigned)(j << 5)));
+        static_for<0, (ICAMD_FUSED_ABLATE & 4) ? 0 : 4>([&](auto jj) {
+          constexpr int j = decltype(jj)::value;
+          // reads return in issue order: dy fragment j is complete once at most 2 * (3 - j) reads are outstanding (the x fragments
+          // were issued first)
+          asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(yf[j]), "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]) : "n"(2 * (3 - j)) : "memory");
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wacc[i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], wacc[i][j0 + j], 0, 0, 0);
-          });
+          for (int i = 0; i < 4; ++i) wacc[h][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[j], wacc[h][i][j], 0, 0, 0);
         });
       }
-      buf = buf == NBUF - 1 ? 0 : buf + 1;
+    };
+
+    // ---- software pipeline: iteration u multiplies the dy of unit u while unit u + 1 is transformed; ONE barrier per unit publishes
+    // both (dy of unit u from the previous iteration's transform, the landed loads of unit u + 1) and frees the buffer of unit u - 1
+    // for the loads of unit u + 3.  The two roles take the two halves of an iteration in OPPOSITE order -- every SIMD hosts one wave
+    // of each role, so one wave's MFMAs and transposed reads run beside the other's BatchNorm arithmetic instead of both queueing for
+    // the same pipe (first form: transform, barrier, multiply in lockstep -- CO = 512 ran 1.7 us per unit against 1.25 us of loads).
+    if (nunits > 0) {
+      wait_vmcnt_dyn(((nunits - 1 < NBUF - 2) ? nunits - 1 : NBUF - 2) * L);     // unit 0 (the prologue's units 1, 2 stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      transform(std::integral_constant<int, 0>{}, 0);
+    }
+    int buf = 0;                           // buffer of unit u
+    for (int t = 0; t < ntiles; ++t) {
+      static_for<0, NH>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        constexpr int hn = (h + 1) % NH;   // half of unit u + 1
+        const int u = t * NH + h;
+        const int nb = buf == NBUF - 1 ? 0 : buf + 1;
+        // ---- this wave's loads of unit u + 1 have landed.  Younger in its queue: the loads of unit u + 2 (one group of L) and, data
+        // gradient, the row stores issued since the loads of unit u + 1 were, i.e. in iterations u - 2 and u - 1 (iteration j issues
+        // one iff it is the first unit of a tile other than the first: j >= NH and j % NH == 0; sb(j) = such iterations <= j)
+        if (u + 1 < nunits) {
+          const int nl = u + 2 < nunits ? 1 : 0;
+          int ns = 0;
+          if constexpr (DG) {
+            const int j1 = u - 1, j0 = u - 3;
+            ns = (j1 < 0 ? 0 : j1 / NH) - (j0 < 0 ? 0 : j0 / NH);
+          }
+          wait_vmcnt_dyn(nl * L + ns);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (u + NBUF - 1 < nunits) stage(u + NBUF - 1, buf == 0 ? NBUF - 1 : buf - 1);
+        if constexpr (DG) {
+          if constexpr (h == 0) {
+            if (t > 0) store_dx(t - 1);
+          }
+          multiply(hc, t, buf);
+          if (u + 1 < nunits) transform(std::integral_constant<int, hn>{}, nb);
+        } else {
+          if (u + 1 < nunits) transform(std::integral_constant<int, hn>{}, nb);
+          multiply(hc, t, buf);
+        }
+        buf = nb;
+      });
     }
 
     // ---- tail: the last dx tile, the filter-gradient slab
@@ -331,16 +409,18 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
     if constexpr (DG) {
       if (ntiles > 0) store_dx(ntiles - 1);
     } else {
-      // wacc[i][j]: rows = input channels 16 i + 4 (lane >> 4) .. + 3, column = output channel (wq CR + j) 16 + (lane & 15)
+      // wacc[h][i][j]: rows = input channels 16 i + 4 (lane >> 4) .. + 3, column = output channel 256 h + (4 wq + j) 16 + (lane & 15)
       float* slab = p.slab + (long long)split * CO * p.CI;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int j = 0; j < CR; ++j) {
-          const int co = (wq * CR + j) * 16 + (lane & 15);
-          const int ci = ci0 + 16 * i + 4 * (lane >> 4);
-          *(f32x4*)(slab + (long long)co * p.CI + ci) = wacc[i][j];
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < CR; ++j) {
+            const int co = h * 256 + (wq * CR + j) * 16 + (lane & 15);
+            const int ci = ci0 + 16 * i + 4 * (lane >> 4);
+            *(f32x4*)(slab + (long long)co * p.CI + ci) = wacc[h][i][j];
+          }
     }
   };
   if (wave < 4) run(std::true_type{});
@@ -381,7 +461,7 @@ int icamd_conv1x1_bn_bwd_fused_launch(FusedBwdParams& p, hipStream_t stream) {
   icamd_conv1x1_bn_bwd_fused_plan(p.M, p.CI, &p.S, &p.rows_per_split);
   p.xcd_pairs = (p.S % 8 == 0 && icamd_num_xccs() == 8) ? 1 : 0;
   const dim3 grid((unsigned)(p.S * p.nslices)), block(512);
-  if (p.CO == 256) hipLaunchKernelGGL((conv1x1_bn_bwd_fused_kernel<256, 4>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((conv1x1_bn_bwd_fused_kernel<512, 2>), grid, block, 0, stream, p);
+  if (p.CO == 256) hipLaunchKernelGGL((conv1x1_bn_bwd_fused_kernel<256>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((conv1x1_bn_bwd_fused_kernel<512>), grid, block, 0, stream, p);
   return icamd_launch_status();
 }
