@@ -30,6 +30,8 @@ int icamd_bn_bwd_apply_launch(const float* part, int nrows, const bf16_t* g, con
                               long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s, int sums_are_gy = 0);
 int icamd_bn_bwd_finalize_launch(const float* part, int nrows, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                  long long rows, int C, int accumulate, double* chunks, float* c1c2, hipStream_t s, int sums_are_gy);
+int icamd_bn_bwd_reduce_launch(const bf16_t* g, const bf16_t* y, const float* mean, const float* invstd, float* part, long long rows,
+                               int C, int* nblk_out, hipStream_t s);
 int icamd_maxpool_fwd_launch(const bf16_t* x, bf16_t* out, unsigned char* idx, int N, int IH, int IW, int C, int OH, int OW,
                              hipStream_t s);
 int icamd_bn_relu_maxpool_fwd_launch(const bf16_t* y, const float* scale, const float* shift, bf16_t* out, unsigned char* idx,
@@ -728,24 +730,39 @@ int icamd_conv1x1_bn_bwd_fused(const icamd_conv_desc* d, const float* partials, 
   ProfScope _prof(PC_FUSED_BWD, stream);
   if (d != nullptr) {
     const ConvWork cw = conv_work(d);
-    _prof.work(2.0 * cw.out + 2.0 * cw.in + 4.0 * cw.w + 8.0 * nrows * d->Cout, 2.0 * cw.flops);   // g, y read; x read, dx written; dw
+    // g, y read (twice when the sums are formed here); x read, dx written; dw
+    _prof.work((partials ? 2.0 : 4.0) * cw.out + 2.0 * cw.in + 4.0 * cw.w + (partials ? 8.0 * nrows * d->Cout : 0.0), 2.0 * cw.flops);
   }
-  if (partials == nullptr || nrows <= 0 || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr ||
+  if ((partials != nullptr && nrows <= 0) || g == nullptr || y == nullptr || mean == nullptr || invstd == nullptr || scale == nullptr ||
       dgamma == nullptr || dbeta == nullptr || x == nullptr || w_t == nullptr || dx == nullptr || dw == nullptr ||
       bn_workspace == nullptr || wgrad_workspace == nullptr)
     return ICAMD_ERR_BAD_ARG;
   if (!icamd_conv1x1_bn_bwd_fused_supported(d)) return ICAMD_ERR_UNSUPPORTED;
   const int C = d->Cout;
-  if (bn_workspace_bytes < icamd_bn_bwd_apply_workspace_bytes(C) ||
+  const long long M = (long long)d->N * d->OH * d->OW;
+  if (bn_workspace_bytes < (partials ? icamd_bn_bwd_apply_workspace_bytes(C) : icamd_bn_bwd_workspace_bytes(M, C)) ||
       wgrad_workspace_bytes < icamd_conv1x1_bn_bwd_fused_workspace_bytes(d))
     return ICAMD_ERR_WORKSPACE;
-  const long long M = (long long)d->N * d->OH * d->OW;
   char* ws = (char*)bn_workspace;
   double* chunks = (double*)(ws + 256);
   ws += bn_chunk_bytes(C);
-  float* c1c2 = (float*)ws;
-  int rc = icamd_bn_bwd_finalize_launch(partials, nrows, mean, invstd, dgamma, dbeta, M, C, accumulate, chunks, c1c2,
-                                        (hipStream_t)stream, 1);
+  int rc;
+  float* c1c2;
+  if (partials != nullptr) {
+    // (sum g, sum g * y) rows left by icamd_conv2d_dgrad_bnred
+    c1c2 = (float*)ws;
+    rc = icamd_bn_bwd_finalize_launch(partials, nrows, mean, invstd, dgamma, dbeta, M, C, accumulate, chunks, c1c2, (hipStream_t)stream, 1);
+  } else {
+    // no sums yet: the reduce pass of icamd_bn_bwd over the (already masked) g and y first; workspace laid out as icamd_bn_bwd's
+    const int rpb = icamd_bn_bwd_rows_per_block(M, C);
+    const long long nblk = (M + rpb - 1) / rpb;
+    float* part = (float*)ws;
+    c1c2 = (float*)(ws + align_up((size_t)nblk * 2 * C * sizeof(float), 256));
+    int nb = 0;
+    rc = icamd_bn_bwd_reduce_launch((const bf16_t*)g, (const bf16_t*)y, mean, invstd, part, M, C, &nb, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = icamd_bn_bwd_finalize_launch(part, nb, mean, invstd, dgamma, dbeta, M, C, accumulate, chunks, c1c2, (hipStream_t)stream, 0);
+  }
   if (rc) return rc;
   FusedBwdParams p;
   memset(&p, 0, sizeof(p));

@@ -982,6 +982,21 @@ int icamd_bn_bwd_dual_launch(const bf16_t* dout, const unsigned char* maskbits, 
   return icamd_launch_status();
 }
 
+// Reduce half of the BatchNorm backward alone, for an output gradient that is ALREADY masked (no ReLU handling): partial rows
+// part[nblk][2][C] = (sum g, sum g * xhat) per block of rows; returns the number of rows written through *nblk_out.
+int icamd_bn_bwd_reduce_launch(const bf16_t* g, const bf16_t* y, const float* mean, const float* invstd, float* part, long long rows,
+                               int C, int* nblk_out, hipStream_t s) {
+  if (C % 8 != 0) return ICAMD_ERR_BAD_ARG;
+  PoolGather pg;
+  memset(&pg, 0, sizeof(pg));
+  const int rpb = icamd_bn_bwd_rows_per_block(rows, C);
+  const int nblk = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g, (const bf16_t*)nullptr, y, mean, invstd, mean, mean,
+                     part, (const unsigned char*)nullptr, rows, C, rpb, 0, pg);
+  *nblk_out = nblk;
+  return icamd_launch_status();
+}
+
 // Finalize half of the BatchNorm backward alone: partial rows -> c1 = mean g, c2 = mean g * xhat (c1c2[0..C), [C..2C)) and the
 // gamma / beta gradients.  The apply half then runs wherever the caller wants it (conv_fused_bwd.hip: inside the convolution's
 // backward kernel).

@@ -758,7 +758,53 @@ class ResNet(PicklableModel):
             yk = next_y()
             y2 = None
             fused_conv3 = False
-            if "down_conv" in blk and _DUAL_BNBWD:
+            shortcut_done = False
+            # may this block's conv1 data gradient hand the PREVIOUS block g = its masked output gradient plus the (sum g, sum g*y)
+            # rows of its last BatchNorm (icamd_conv2d_dgrad_bnred)?  Identity blocks always take them; a projection block only
+            # through the fused conv3 + bn3 backward (its other path, icamd_bn_bwd_dual, wants the unmasked gradient and no sums)
+            prev_takes_g = False
+            if bi > 0 and self.block == "bottleneck":
+                pblk = self.blocks[bi - 1]
+                if "down_conv" not in pblk:
+                    prev_takes_g = True
+                else:
+                    dp3 = pblk["convs"][-1].desc(N, h, w)
+                    prev_takes_g = bool(lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(dp3)))
+            d3 = convs[-1].desc(N, *hw_in[-1])
+            fuse3 = (self.block == "bottleneck" and fused_rows > 0
+                     and bool(lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(d3))))
+
+            def fused_conv_bn(conv, bn, dsc, partials, nrows, y_t, x_ptr, dx_ptr, bn_ws, bn_ws_bytes):
+                """BatchNorm-backward apply + data gradient + weight gradient of `conv` -> `bn` in one pass over g (= dout, already
+                masked) and y (round 5, icamd_conv1x1_bn_bwd_fused); main stream, its own slab workspace (the side stream's weight
+                gradients own ws["wgrad_ws"])."""
+                st_ = self.stat_arena.data_ptr() + 4 * bn.stat_offset
+                c_ = bn.c
+                need = lib.icamd_conv1x1_bn_bwd_fused_workspace_bytes(ctypes.byref(dsc))
+                fws = ws.get("fused_ws")
+                if fws is None or fws.numel() < need:
+                    fws = ws["fused_ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                hip.check(lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(dsc), partials, nrows, dout, y_t.data_ptr(), st_, st_ + 4 * c_,
+                                                         st_ + 8 * c_, self._gf(bn.weight), self._gf(bn.bias), x_ptr, self._wt(conv),
+                                                         dx_ptr, self._gf(conv.w), acc, bn_ws, bn_ws_bytes, fws.data_ptr(),
+                                                         fws.numel(), s), bn.name + " + " + conv.name + " bwd (fused)")
+
+            if "down_conv" in blk and fuse3:
+                # projection block whose successor left g and the (sum g, sum g*y3) rows: conv3 + bn3 fused; the shortcut's BatchNorm
+                # takes the same g -- its convolution + BatchNorm fused as well where it is a 1x1 / stride-1 layer of a routed
+                # shape (layer1.0), else its BatchNorm backward alone (no mask: g is masked already)
+                fused_conv_bn(convs[-1], bns[-1], d3, ws["bnb_part"].data_ptr(), fused_rows, b["y"][-1],
+                              b["a"][nconv - 2].data_ptr(), DA, ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"])
+                fused_conv3 = True
+                dc = blk["down_conv"]
+                ddc = dc.desc(N, h, w)
+                if dc.stride == 1 and lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(ddc)):
+                    fused_conv_bn(dc, blk["down_bn"], ddc, None, 0, b["yd"], xin.data_ptr(), T, bws, bwb)
+                    shortcut_done = True
+                else:
+                    y2 = next_y()
+                    bn_bwd(blk["down_bn"], dout, None, b["yd"], ypool[y2], None, False)
+            elif "down_conv" in blk and _DUAL_BNBWD:
                 # the block's last BatchNorm and its shortcut's BatchNorm take the same masked gradient: one reduce and one
                 # apply pass for both (dout and the mask bits are read twice instead of four times)
                 y2 = next_y()
@@ -775,21 +821,11 @@ class ResNet(PicklableModel):
                 bnl = bns[-1]
                 stl = self.stat_arena.data_ptr() + 4 * bnl.stat_offset
                 cl = bnl.c
-                d3 = convs[-1].desc(N, *hw_in[-1])
-                if self.block == "bottleneck" and lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(d3)):
-                    # conv3 + bn3 backward in one pass over g and y3 (round 5): BatchNorm finalize from the partial sums, dy3 only in
-                    # LDS, d(a2) -> DA and the filter gradient out of the same launch; main stream (its own slab workspace: the
-                    # side stream's weight gradients own ws["wgrad_ws"])
-                    fws = ws.get("fused_ws")
-                    need = lib.icamd_conv1x1_bn_bwd_fused_workspace_bytes(ctypes.byref(d3))
-                    if fws is None or fws.numel() < need:
-                        fws = ws["fused_ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
-                    hip.check(lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(d3), ws["bnb_part"].data_ptr(), fused_rows, dout,
-                                                             b["y"][-1].data_ptr(), stl, stl + 4 * cl, stl + 8 * cl,
-                                                             self._gf(bnl.weight), self._gf(bnl.bias), b["a"][nconv - 2].data_ptr(),
-                                                             self._wt(convs[-1]), DA, self._gf(convs[-1].w), acc,
-                                                             ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"], fws.data_ptr(),
-                                                             fws.numel(), s), bnl.name + " + " + convs[-1].name + " bwd (fused)")
+                if fuse3:
+                    # conv3 + bn3 backward in one pass over g and y3: BatchNorm finalize from the partial sums, dy3 only in LDS,
+                    # d(a2) -> DA and the filter gradient out of the same launch
+                    fused_conv_bn(convs[-1], bnl, d3, ws["bnb_part"].data_ptr(), fused_rows, b["y"][-1],
+                                  b["a"][nconv - 2].data_ptr(), DA, ws["bna_ws"].data_ptr(), ws["bna_ws_bytes"])
                     fused_conv3 = True
                 else:
                     hip.check(lib.icamd_bn_bwd_from_gy_partials(ws["bnb_part"].data_ptr(), fused_rows, dout, b["y"][-1].data_ptr(),
@@ -815,7 +851,10 @@ class ResNet(PicklableModel):
                 yk = next_y()
                 bn_bwd(bns[i - 1], DA, None, b["y"][i - 1], ypool[yk], None, True)
             wgrad(convs[0], xin.data_ptr(), ypool[yk], N, h, w, ybuf=yk)
-            if "down_conv" in blk:
+            if shortcut_done:
+                # the shortcut's filter gradient is done and T holds its (full-size) data gradient
+                dgrad(convs[0], ypool[yk], other, T, N, h, w)
+            elif "down_conv" in blk:
                 if y2 is None:
                     y2 = next_y()
                     bn_bwd(blk["down_bn"], dout, None, b["yd"], ypool[y2], None, True, mask)   # "relu" = the block's mask bits
@@ -833,7 +872,7 @@ class ResNet(PicklableModel):
                     hip.check(lib.icamd_conv2d_dgrad(ctypes.byref(d1), ypool[y2], self._wt(dc), T, None, None, s),
                               dc.name + " dgrad (even grid)")
                     d0 = convs[0].desc(N, h, w)
-                    if (bi > 0 and "down_conv" not in self.blocks[bi - 1] and self.block == "bottleneck"
+                    if (prev_takes_g and self.block == "bottleneck"
                             and lib.icamd_conv2d_dgrad_bnred_supported(ctypes.byref(d0))):
                         pb = ws["blocks"][bi - 1]   # (see the identity-shortcut case below)
                         hip.check(lib.icamd_conv2d_dgrad_bnred(ctypes.byref(d0), ypool[yk], self._wt(convs[0]), other, T, None, 1,
@@ -849,7 +888,7 @@ class ResNet(PicklableModel):
                     dgrad(convs[0], ypool[yk], other, T, N, h, w)
             else:
                 d0 = convs[0].desc(N, h, w)
-                if (bi > 0 and "down_conv" not in self.blocks[bi - 1] and self.block == "bottleneck"
+                if (prev_takes_g and self.block == "bottleneck"
                         and lib.icamd_conv2d_dgrad_bnred_supported(ctypes.byref(d0))):
                     # `other` becomes g of the previous block (its ReLU mask applied, which every consumer of d(block output)
                     # applies anyway) and the sums its last BatchNorm's backward needs come out of the same launch

@@ -201,6 +201,9 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
  * d describes the convolution (1x1, stride 1, no padding); x is its input, w_t its transposed filter [Cin][Cout]; g, y are
  * [N,OH,OW,Cout] (g already masked by the block's ReLU bits).  bn_workspace as icamd_bn_bwd_from_gy_partials
  * (icamd_bn_bwd_apply_workspace_bytes(Cout), zero-filled once); wgrad_workspace >= icamd_conv1x1_bn_bwd_fused_workspace_bytes(d).
+ * partials == NULL: no sums exist yet -- the call first runs icamd_bn_bwd's reduce pass over g and y (bn_workspace then as
+ * icamd_bn_bwd's: icamd_bn_bwd_workspace_bytes(N*OH*OW, Cout), zero-filled once); used for a projection shortcut's 1x1 / stride-1
+ * convolution + BatchNorm, whose output gradient is the block's g as well.
  * _supported: 1 for (Cin, Cout) = (64, 256) and (128, 512) with >= 16384 pixels; elsewhere the caller keeps
  * icamd_bn_bwd_from_gy_partials + icamd_conv2d_dgrad + icamd_conv2d_wgrad, which compute the same three results. */
 int icamd_conv1x1_bn_bwd_fused_supported(const icamd_conv_desc* d);

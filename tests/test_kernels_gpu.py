@@ -1339,6 +1339,24 @@ def test_conv1x1_bn_bwd_fused(lib, case):
     assert R.max_bf16_ulp(dx.float().cpu(), dx3.float().cpu()) <= 1.0
     assert float((dx != dx3).float().mean()) <= 2e-2
     assert R.rel_l2(dw.cpu(), dw3.cpu()) <= 1e-5
+    # partials == NULL: the call forms the sums itself (icamd_bn_bwd's reduce pass; workspace as icamd_bn_bwd's) -- the projection
+    # shortcut's convolution + BatchNorm, for which no data gradient has left sums
+    b2b = lib.icamd_bn_bwd_workspace_bytes(M, Cout)
+    b2 = torch.zeros(b2b, dtype=torch.uint8, device=DEV)
+    dx4 = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dw4 = torch.full((Cout, Cin), float("nan"), device=DEV)
+    dg4, db4 = torch.full((Cout,), float("nan"), device=DEV), torch.full((Cout,), float("nan"), device=DEV)
+    assert lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(d), None, 0, hip.ptr(gd), hip.ptr(yd), hip.ptr(md), hip.ptr(isd), hip.ptr(scd),
+                                          hip.ptr(dg4), hip.ptr(db4), hip.ptr(xd), hip.ptr(wtd), hip.ptr(dx4), hip.ptr(dw4), 0,
+                                          hip.ptr(b2), b2b, hip.ptr(ws), wsb, s) == 0
+    sync()
+    got4 = dx4.float().cpu()
+    assert torch.isfinite(got4).all() and R.rel_l2(got4, rdx) <= 1e-3 and R.bf16_close(got4, rdx)
+    assert R.rel_l2(dw4.cpu().reshape(Cout, 1, 1, Cin), rdw) <= 1e-3
+    assert R.rel_l2(dg4.cpu(), rdgamma) <= 1e-4 and R.rel_l2(db4.cpu(), rdbeta) <= 1e-4
+    assert lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(d), None, 0, hip.ptr(gd), hip.ptr(yd), hip.ptr(md), hip.ptr(isd), hip.ptr(scd),
+                                          hip.ptr(dg4), hip.ptr(db4), hip.ptr(xd), hip.ptr(wtd), hip.ptr(dx4), hip.ptr(dw4), 0,
+                                          hip.ptr(bws), bwsb, hip.ptr(ws), wsb, s) == 3      # the small workspace does not do
     # shapes without this form are refused (the caller keeps the three launches)
     d2 = hip.conv_desc(2, 14, 14, 256, 1024, 1, 1, 1, 0)
     assert lib.icamd_conv1x1_bn_bwd_fused_supported(ctypes.byref(d2)) == 0
