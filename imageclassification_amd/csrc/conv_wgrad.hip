@@ -484,6 +484,207 @@ __global__ __launch_bounds__(64 * WK * WC, WPS) void conv_wgrad_ring_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, eight phases per pair of 64-row reduction tiles: gemm_nt.hip's 8-phase schedule (cdna_hip_programming.md "The
+// 256^2 8-phase template") carried to the weight gradient of pointwise layers (round 5; ViT-B/16's Linear layers: M = 50 432 rows,
+// 768 x {768, 2304, 3072} filters -- the ring kernel above ran them at 700-765 TFLOP/s where the 8-phase GEMM does 850-920 on the
+// same shapes).  D[kk][co] = sum_m X[m][kk] dY[m][co]:
+//   * 8 waves, wr = wave >> 2 owns filter columns kk wr*128 .. +128, wc = wave & 3 output channels co wc*64 .. +64: 128 x 64 fp32
+//     accumulators per wave = four QUADRANTS of 64 kk x 32 co, one per phase: 16 MFMAs (4 kk fragments x 2 co fragments x 2 steps of
+//     32 rows) between two raw s_barriers;
+//   * a reduction tile = 64 rows of both operands, staged as four PIECES of 16 KB cut along what a phase starts to need:
+//       X_h0 = columns {wr*128 + [0, 64)}   (phase 1)      dY_n0 = channels {wc*64 + [0, 32)}  (phase 1, kept for phase 4)
+//       dY_n1 = channels {wc*64 + [32, 64)} (phase 2)      X_h1 = columns {wr*128 + [64, 128)} (phase 3)
+//     a piece = [64 rows][256 B] -- whole 128 B (X) / 64 B (dY) segments of an operand row per 8 / 4 lanes, 32 B blocks XOR-swizzled
+//     by key(row) = row[1:0] | row[3] << 2 on the source side -- read with ds_read_b64_tr_b16 (the reduction index is the slow
+//     memory dimension of both operands: no transposed copy is ever made).  A lane's two reads of a fragment are 4 rows = 1 KiB apart
+//     with the SAME key, fragments differ in the block bits only: one address register per fragment and buffer, everything else is
+//     the instruction's immediate offset;
+//   * LDS holds two reduction tiles (128 KB); every phase issues ONE piece, six pieces ahead, with a scalar base (the tile's first
+//     row) and a 32-bit per-lane offset; counted s_waitcnt vmcnt(6); the two wave groups run one barrier apart (gemm_nt.hip).
+// Requires whole tiles: Ktot, Cout multiples of 256, rows per split multiples of 64 (the launcher falls back to the ring kernel).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int W8_PIECE = 16384, W8_KTILE = 65536;
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void w8_glds16_sbase(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ void w8_wait_pieces_younger(int n) {   // leave the n youngest pieces (2 LDS-DMA each) in flight
+  if (n >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// both transposed reads of one fragment: rows r and r + 4 (1 KiB further) of a 256 B-row piece
+template <int OFF>
+__device__ __forceinline__ bf16x8 w8_tr_frag(unsigned a) {
+  static_assert(OFF >= 0 && OFF + 1024 < 65536, "ds_read offset is a 16-bit field");
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(OFF + 1024));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_8phase_kernel(const WgradParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * W8_KTILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  unsigned int tile;
+  int split;
+  wgrad_block_order(p, tile, split);
+  const int tile_c = (int)(tile % (unsigned)p.ntiles_c), tile_k = (int)(tile / (unsigned)p.ntiles_c);
+  const int k0 = tile_k * 256, c0 = tile_c * 256;
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int nk = (m_end - m_begin) >> 6;            // whole 64-row reduction tiles (launcher)
+  const int last_piece = 4 * nk - 1;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LPTR(smem));
+  const unsigned xpitch = (unsigned)p.Cin * 2u, ypitch = (unsigned)p.Cout * 2u;
+  const unsigned char* const Xb = (const unsigned char*)p.x + (size_t)m_begin * xpitch;
+  const unsigned char* const Yb = (const unsigned char*)p.dy + (size_t)m_begin * ypitch;
+
+  // ---- transposed-read roles: 16-lane group g4 reads rows 8 g4 + q (and + 4), 8 B at 8 pq inside a 32 B block; key(row) is a lane
+  // constant (rows advance by 32 per step and by 4 between the two reads: bits 0, 1 and 3 never change)
+  const int g4 = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const int r0 = 8 * g4 + q;
+  const int key = (r0 & 3) | (((r0 >> 3) & 1) << 2);
+  unsigned aX[2][4], aY[2][2];     // [reduction-tile buffer][fragment]
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aX[b][i] = lds_base + (unsigned)(b * W8_KTILE + r0 * 256 + (((wr * 4 + i) ^ key) << 5) + 8 * pq);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) aY[b][j] = lds_base + (unsigned)(b * W8_KTILE + r0 * 256 + (((wc * 2 + j) ^ key) << 5) + 8 * pq);
+  }
+
+  // ---- staging roles: instruction j of this wave is instruction qi = wave * 2 + j of a piece: piece rows qi * 4 .. + 4, sixteen
+  // lanes per row; the lane's 16 B chunk pc holds the operand's chunk pc ^ (key(row) << 1) of the piece row
+  unsigned off[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wave * 2 + j) * 4 + (lane >> 4);
+      const int lc = (lane & 15) ^ ((((r & 3) | (((r >> 3) & 1) << 2))) << 1);
+      const bool isX = (t == 0 || t == 3);
+      if (isX) off[t][j] = (unsigned)r * xpitch + (unsigned)(k0 + (lc >> 3) * 128 + (t == 3 ? 64 : 0) + (lc & 7) * 8) * 2u;
+      else off[t][j] = (unsigned)r * ypitch + (unsigned)(c0 + (lc >> 2) * 64 + (t == 2 ? 32 : 0) + (lc & 3) * 8) * 2u;
+    }
+  auto stage1 = [&](auto tc, auto bc, auto jc, int ktile) {   // instruction J of piece type T of reduction tile `ktile` into buffer B
+    constexpr int T = decltype(tc)::value, B = decltype(bc)::value, J = decltype(jc)::value;
+    const unsigned char* kb = (T == 0 || T == 3) ? Xb + (size_t)ktile * 64 * xpitch : Yb + (size_t)ktile * 64 * ypitch;
+    w8_glds16_sbase(kb, off[T][J], lds_base + (unsigned)(B * W8_KTILE + T * W8_PIECE + (wave * 2 + J) * 1024));
+  };
+  // prologue: pieces 0..5 (the whole first reduction tile and the first half of the second)
+  static_for<0, 6>([&](auto sc) {
+    constexpr int S = decltype(sc)::value;
+    if (S < 4 || nk > 1) {
+      stage1(std::integral_constant<int, (S & 3)>{}, std::integral_constant<int, (S >> 2)>{}, std::integral_constant<int, 0>{}, S >> 2);
+      stage1(std::integral_constant<int, (S & 3)>{}, std::integral_constant<int, (S >> 2)>{}, std::integral_constant<int, 1>{}, S >> 2);
+    }
+  });
+  w8_wait_pieces_younger((nk > 1 ? 5 : 3) - 1);      // pieces 0 and 1 have landed (this wave's part)
+
+  f32x4 acc[4][8];     // [co fragment][kk fragment]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient (column sums of dY): the workgroups of the first filter-column tile multiply the dY fragments of ONE channel half
+  // per wave (wr = 0: half 0, wr = 1: half 1 -- 4 more MFMAs per reduction tile in either wave group) by an all-ones operand
+  const bool do_bias = p.bias_slab != nullptr && tile_k == 0;
+  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // the stagger: group 1 runs one barrier behind group 0
+  bf16x8 af[8], b0[4], b1[4];   // X fragments [step*4 + i] of the current column half; dY fragments [step*2 + j] of both channel halves
+
+  auto phase = [&](auto phc, auto steadyc, int g) {
+    constexpr int PH = decltype(phc)::value;       // 0..7: reduction-tile parity PH >> 2, phase PH & 3
+    constexpr bool STEADY = decltype(steadyc)::value;
+    constexpr int BUF = PH >> 2, P = PH & 3;
+    // ---- load section: the fragments this phase starts to need, then the wait that retires what the NEXT phase reads
+    if constexpr (P == 0) {
+      static_for<0, 8>([&](auto c) { constexpr int x = decltype(c)::value; af[x] = w8_tr_frag<0 * W8_PIECE + (x >> 2) * 8192>(aX[BUF][x & 3]); });
+      static_for<0, 4>([&](auto c) { constexpr int x = decltype(c)::value; b0[x] = w8_tr_frag<1 * W8_PIECE + (x >> 1) * 8192>(aY[BUF][x & 1]); });
+    } else if constexpr (P == 1) {
+      static_for<0, 4>([&](auto c) { constexpr int x = decltype(c)::value; b1[x] = w8_tr_frag<2 * W8_PIECE + (x >> 1) * 8192>(aY[BUF][x & 1]); });
+    } else if constexpr (P == 2) {
+      static_for<0, 8>([&](auto c) { constexpr int x = decltype(c)::value; af[x] = w8_tr_frag<3 * W8_PIECE + (x >> 2) * 8192>(aX[BUF][x & 3]); });
+    }
+    // pieces <= g + 2 (what phase g + 1 starts to read) have landed; issued so far: pieces <= g + 5
+    if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else w8_wait_pieces_younger((g + 5 < last_piece ? g + 5 : last_piece) - (g + 2));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
+                   "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute section: one quadrant, 16 MFMAs; among them the phase's piece (g + 6: type (PH + 2) & 3, reduction tile (g + 6) >> 2)
+    constexpr int MH = (P >= 2) ? 1 : 0, NH = (P == 1 || P == 2) ? 1 : 0;
+    const bool do_stage = STEADY || g + 6 <= last_piece;
+    const int ktile = (g + 6) >> 2;
+    __builtin_amdgcn_s_setprio(1);
+    static_for<0, 16>([&](auto mc) {
+      constexpr int x = decltype(mc)::value;
+      constexpr int ks = x >> 3, i = (x >> 1) & 3, j = x & 1;
+      if constexpr (x == 3 || x == 10) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_stage) stage1(std::integral_constant<int, ((PH + 2) & 3)>{}, std::integral_constant<int, (((PH + 6) >> 2) & 1)>{},
+                             std::integral_constant<int, (x == 3 ? 0 : 1)>{}, ktile);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[NH * 2 + j][MH * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks * 4 + i], NH ? b1[ks * 2 + j] : b0[ks * 2 + j],
+                                                                           acc[NH * 2 + j][MH * 4 + i], 0, 0, 0);
+    });
+    if constexpr (P == 0 || P == 1) {
+      if (do_bias && wr == P) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          bacc[x & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, P ? b1[x] : b0[x], bacc[x & 1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  int g = 0;
+  int t = 0;
+  for (; t + 2 <= nk && g + 13 <= last_piece; t += 2) {   // both reduction tiles' phases stage pieces that exist
+    static_for<0, 8>([&](auto phc) { phase(phc, std::true_type{}, g + decltype(phc)::value); });
+    g += 8;
+  }
+  for (; t + 2 <= nk; t += 2) {
+    static_for<0, 8>([&](auto phc) { phase(phc, std::false_type{}, g + decltype(phc)::value); });
+    g += 8;
+  }
+  if (nk & 1) static_for<0, 4>([&](auto phc) { phase(phc, std::false_type{}, g + decltype(phc)::value); });
+  if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the two groups
+
+  // D[kk][co]: lane holds co = lane & 15, kk = 4 * (lane >> 4) + reg of a 16 x 16 tile -> one 16 B fp32 store per fragment
+  float* slab = p.slab + (long long)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      const int co = c0 + wc * 64 + jj * 16 + (lane & 15);
+      const int kk = k0 + wr * 128 + ii * 16 + 4 * (lane >> 4);
+      *(f32x4*)(slab + (long long)co * p.Ktot + kk) = acc[jj][ii];
+    }
+  if (do_bias && (lane >> 4) == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) p.bias_slab[(long long)split * p.Cout + c0 + wc * 64 + wr * 32 + j * 16 + (lane & 15)] = bacc[j][0];
+  }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]; 16 B per lane; fixed summation order.
 // A block owns OUTS consecutive float4 outputs and splits the S slabs over 256/OUTS slab lanes (4 loads in
 // flight per thread), then folds the lanes through LDS in lane order.
@@ -738,7 +939,8 @@ void icamd_wgrad_tile(long long M, int Ktot, int Cout, int* bmk, int* bnc) {
   // barrier rate: they stay on the single-stage 128 / 64 tiles.
   // (round 3) also the >= 50 GFLOP pointwise layers whose sides are multiples of 64 but not of 256 -- ConvNeXt-T's 192 <-> 768
   // and 384 <-> 1536 Linear layers -- on the 128 x 256 / 256 x 128 ring shapes: 130-140 -> 112-124 us and 100-104 -> 87-91 us.
-  const bool work = (double)M * Ktot * Cout >= 2.5e10;
+  static const double work_floor = [] { const char* e = getenv("ICAMD_WGRAD_WORK"); return e ? atof(e) : 2.5e10; }();   // (A/B runs)
+  const bool work = (double)M * Ktot * Cout >= work_floor;
   const bool both256 = Ktot % 256 == 0 && Cout % 256 == 0;
   const bool wide = Ktot % 64 == 0 && Cout % 64 == 0 && (Ktot < Cout ? Ktot : Cout) >= 192 &&
                     (pick_side(Ktot) == 256 || pick_side(Cout) == 256);
@@ -785,7 +987,8 @@ void icamd_wgrad_plan(int M, int Cout, int Ktot, int* S, int* rows_per_split) {
   }
   const int resident = 256 * wgs_per_cu(bmk, bnc);
   static const int overhead_rows = []() { const char* e = getenv("ICAMD_WGRAD_OVERHEAD_ROWS"); return e ? atoi(e) : 256; }();
-  const int gran = RKR;
+  // 256 x 256 tiles: whole 64-row reduction tiles per split, what the 8-phase kernel walks (the ring kernel takes any multiple of 32)
+  const int gran = (bmk == 256 && bnc == 256) ? 64 : RKR;
   int scap = (M + gran - 1) / gran;
   const int smax = (8 * resident + tiles - 1) / tiles;
   if (scap > smax) scap = smax;
@@ -860,6 +1063,13 @@ int icamd_wgrad_launch(WgradParams& p, hipStream_t stream) {
   if (!use_ring(bmk, bnc)) {
     if (bmk == 64) return bnc == 64 ? launch<64, 64>(p, stream) : launch<64, 128>(p, stream);
     return bnc == 64 ? launch<128, 64>(p, stream) : launch<128, 128>(p, stream);
+  }
+  // 256 x 256 tiles of pointwise layers with whole tiles everywhere: the 8-phase kernel (ICAMD_WGRAD_8PHASE=0: the ring kernel, A/B)
+  static const int eight = [] { const char* e = getenv("ICAMD_WGRAD_8PHASE"); return e ? atoi(e) : 1; }();
+  if (eight && bmk == 256 && bnc == 256 && p.pointwise && p.Ktot % 256 == 0 && p.Cout % 256 == 0 && p.M % 64 == 0 &&
+      p.rows_per_split % 64 == 0 && (long long)p.M * p.Cin < (1ll << 30) && (long long)p.M * p.Cout < (1ll << 30)) {
+    hipLaunchKernelGGL(conv_wgrad_8phase_kernel, dim3((unsigned)(p.ntiles_k * p.ntiles_c * p.S)), dim3(512), 0, stream, p);
+    return icamd_launch_status();
   }
   //                                         BMK  BNC  WK WC NSLOT WPS   per wave   LDS/workgroup  workgroups/CU
   if (bmk == 256 && bnc == 256) return launch_ring<256, 256, 2, 4, 4, 2>(p, stream);   // 128x64     128 KB         1

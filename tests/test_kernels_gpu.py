@@ -495,7 +495,11 @@ WGRAD_CASES = CONV_CASES + [(8, 28, 28, 64, 64, 3, 1, 1), (2, 30, 30, 128, 256, 
                             # 3x3 / stride 1 with channel counts multiples of 64: the halo-staged kernel (image borders, chunks
                             # that straddle rows and images, ragged last chunk, several chunks per split, tiny images)
                             (2, 9, 7, 64, 128, 3, 1, 1), (3, 7, 7, 128, 64, 3, 1, 1), (5, 10, 13, 64, 64, 3, 1, 1),
-                            (1, 2, 2, 64, 64, 3, 1, 1), (24, 28, 28, 64, 64, 3, 1, 1), (300, 7, 7, 128, 128, 3, 1, 1)]
+                            (1, 2, 2, 64, 64, 3, 1, 1), (24, 28, 28, 64, 64, 3, 1, 1), (300, 7, 7, 128, 128, 3, 1, 1),
+                            # pointwise, both sides multiples of 256, rows a multiple of 64: in the forced-ring child these are the
+                            # 8-phase kernel's shapes (round 5) -- one reduction tile, an odd and an even number per split, 9 tiles
+                            (1, 8, 8, 256, 256, 1, 1, 0), (1, 24, 16, 256, 512, 1, 1, 0), (4, 16, 16, 512, 256, 1, 1, 0),
+                            (1, 65, 64, 768, 768, 1, 1, 0)]
 
 
 def test_conv_wgrad_every_ring_tile_shape():
