@@ -603,3 +603,17 @@ def test_committed_bench_lines_keep_the_contract(name, batch):
     pmc = {"r04_bench_n1.json": "r04_pmc_traffic.json", "r04_bench_eval.json": "r04_pmc_traffic_eval.json",
            "r04_bench_vit.json": "r04_pmc_traffic_vit.json", "r04_bench_convnext.json": "r04_pmc_traffic_convnext.json"}[name]
     assert json.load(open(os.path.join(ROOT, "profiles", pmc)))["kernel_source_hash"] == d["kernel_source_hash"]
+
+
+def test_foreign_codeobj_guard_reports_the_mapped_rccl():
+    """bench.py's op_sel hazard guard for code objects this repository does not build: the RCCL library the
+    process maps is identified by sha256 against the lint record of tools/lint_foreign_codeobj.sh; only a byte-identical, hit-free
+    library reads "clean", anything else says it is unverified (never silently fine)."""
+    import bench
+    from imageclassification_amd import hip
+    lib = hip.load()
+    g = bench.foreign_codeobj_guard(lib)
+    assert set(g) == {"rccl_version", "rccl_library", "verdict"}
+    assert g["verdict"].startswith(("clean:", "unverified:", "HAZARD:"))
+    if lib.icamd_rccl_available():
+        assert g["rccl_version"] > 0 and g["rccl_library"] and "librccl" in g["rccl_library"]
