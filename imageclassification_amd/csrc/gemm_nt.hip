@@ -556,7 +556,10 @@ int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream) {
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
   const long long tiles = (long long)((p.M + TM - 1) / TM) * p.ntiles_n;
-  static const int out_policy = [] { const char* e = getenv("ICAMD_GEMM_OUT_POLICY"); return e ? atoi(e) : 0; }();
+  // output stores non-temporal by default (round 5): the output tile is never re-read by this kernel, and as plain stores the 32
+  // resident workgroups' 128 KB tiles competed with the operand lines their XCD shares (ViT-B/16 36.84 -> 36.30-36.33 ms in two A/B
+  // pairs on one box, ConvNeXt-T neutral; isolated N = 2304 / K = 768: 850 -> 887 TFLOP/s).  ICAMD_GEMM_OUT_POLICY=0: plain, 1: sc1.
+  static const int out_policy = [] { const char* e = getenv("ICAMD_GEMM_OUT_POLICY"); return e ? atoi(e) : 2; }();
   p.out_policy = out_policy;
   if (eight) {
     static const int gn = [] { const char* e = getenv("ICAMD_GEMM_GROUP_N"); return e ? atoi(e) : 4; }();
