@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round evidence, part A / B (one gpurun call each: a call is capped at 20 minutes).  Run on the GPU box from the repo root:
-#   ROUND=r04 bash tools/profile_round.sh A     bench lines of the three model families + rocprofv3 kernel stats
-#   ROUND=r04 bash tools/profile_round.sh C     the three bench lines again, once part B's summaries are in profiles/
-#   ROUND=r04 bash tools/profile_round.sh B     PMC passes (HBM traffic per arch, MFMA busy), per-layer / GEMM / depthwise tables
+#   ROUND=r05 bash tools/profile_round.sh A     bench lines of the three model families + rocprofv3 kernel stats
+#   ROUND=r05 bash tools/profile_round.sh C     the three bench lines again, once part B's summaries are in profiles/
+#   ROUND=r05 bash tools/profile_round.sh B     PMC passes (HBM traffic per arch, MFMA busy), per-layer / GEMM / depthwise tables
 # then, here: python tools/summarize_profiles.py gpurun_out/prof_r04 r04
 PART=${1:-A}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_${ROUND:-r04}
+O=$R/gpurun_out/prof_${ROUND:-r05}
 mkdir -p $O
 VIT="--arch vit_base_patch16_224"
 CNX="--arch convnext_tiny --mixup"
@@ -67,6 +67,10 @@ else
   python3 tools/bench_dwconv.py > $O/dwconv.txt 2>&1
   python3 tools/bench_cnx_layers.py 256 10 2>&1 | grep -v amdgpu.ids > $O/cnx_layers.txt
   python3 tools/bench_attn.py 256 20 2>&1 | grep -v amdgpu.ids > $O/attention.txt
+  # round 5: the fused conv3 + bn3 backward against the three launches it replaces; the Linear-layer weight gradients (8-phase vs ring)
+  python3 tools/fused_bwd_probe.py 20 2>&1 | grep -v amdgpu.ids > $O/fused_bwd.txt
+  for e in 1 0; do for s in "50432 768 3072" "50432 3072 768" "50432 768 2304" "50432 768 768" "12544 768 3072" "50176 1024 512"; do
+    echo -n "ICAMD_WGRAD_8PHASE=$e "; ICAMD_WGRAD_8PHASE=$e python3 tools/wgrad_probe.py $s 2>&1 | grep TFLOP; done; done > $O/wgrad_shapes.txt
   # 10 steps per PMC run: 1 warm-up + 3 timed + the 3-step host-enqueue burst + 3 in the per-class timing pass
   python3 tools/pmc_traffic.py $(find $RAW/pmc_fetch_r50 -name "*.db" | head -1) $(find $RAW/pmc_write_r50 -name "*.db" | head -1) 10 $O/pmc_traffic_r50.json resnet50 256
   python3 tools/pmc_traffic.py $(find $RAW/pmc_fetch_vit -name "*.db" | head -1) $(find $RAW/pmc_write_vit -name "*.db" | head -1) 10 $O/pmc_traffic_vit.json vit_base_patch16_224 256
