@@ -133,8 +133,10 @@ CLASS_KERNELS = {
     # round 5: BatchNorm-backward apply + data gradient + weight gradient of a bottleneck's conv3 in one launch (its finalize and
     # slab fold are launched by the same C-ABI call and counted in its time; they carry the bn_bwd_ / slab_reduce names)
     "conv_bn_bwd_fused": ("conv1x1_bn_bwd_fused_kernel",),
+    # round 5: BatchNorm apply + shortcut + ReLU of a block's end and the next block's 1x1 convolution (+ statistics) in one launch
+    "bn_apply_conv_fused": ("bn_apply_conv1x1_fused_kernel",),
 }
-MFMA_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "attn_fwd", "attn_bwd", "conv_bn_bwd_fused")
+MFMA_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "attn_fwd", "attn_bwd", "conv_bn_bwd_fused", "bn_apply_conv_fused")
 
 
 def kernel_source_hash():

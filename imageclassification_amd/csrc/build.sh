@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../include"
-UNITS="conv_igemm conv3x3_halo conv1x1_resident conv_fused_bwd conv_stem conv_wgrad norm_pool loss_optim token_ops attention dwconv gemm_nt image_ops collective capi"
+UNITS="conv_igemm conv3x3_halo conv1x1_resident conv_fused_bwd conv_fused_fwd conv_stem conv_wgrad norm_pool loss_optim token_ops attention dwconv gemm_nt image_ops collective capi"
 asm_of() { echo "build/$1-hip-amdgcn-amd-amdhsa-gfx950.s"; }
 OBJS=""
 ASMS=""

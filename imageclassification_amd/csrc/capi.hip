@@ -104,7 +104,7 @@ int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base
 #include <vector>
 namespace {
 enum ProfClass { PC_IGEMM_FWD = 0, PC_IGEMM_DGRAD, PC_WGRAD, PC_BN_FINALIZE, PC_BN_APPLY, PC_BN_BWD, PC_POOL, PC_PACK,
-                 PC_LOSS, PC_OPTIM, PC_MISC, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_ELEMWISE, PC_DWCONV, PC_FUSED_BWD, PC_COUNT };
+                 PC_LOSS, PC_OPTIM, PC_MISC, PC_ATTN_FWD, PC_ATTN_BWD, PC_LN_FWD, PC_LN_BWD, PC_ELEMWISE, PC_DWCONV, PC_FUSED_BWD, PC_FUSED_FWD, PC_COUNT };
 // Besides the elapsed time every call books its ALGORITHMIC work (round 4): bytes = each operand tensor of the call
 // read once and each result written once at the stored width (bf16 activations, fp32 parameters / gradients), two-pass
 // kernels counted as the two passes they are; flops = 2 x multiply-adds of the contraction.  bench.py divides by the time.
@@ -708,6 +708,32 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
   ws += bn_chunk_bytes(C);
   return icamd_bn_bwd_apply_launch(partials, nrows, (const bf16_t*)g, (const bf16_t*)y, mean, invstd, scale, dgamma, dbeta,
                                    (bf16_t*)dy, rows, C, accumulate, chunks, (float*)ws, (hipStream_t)stream, 1);
+}
+
+// ---- fused forward across a bottleneck boundary (conv_fused_fwd.hip) --------------------------------------------------
+int icamd_bn_apply_conv1x1_fused_supported(const icamd_conv_desc* d) {
+  if (!conv_desc_ok(d) || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0) return 0;
+  return icamd_bn_apply_conv1x1_fused_wanted((long long)d->N * d->OH * d->OW, d->Cin, d->Cout) ? 1 : 0;
+}
+
+int icamd_bn_apply_conv1x1_fused(const icamd_conv_desc* d, const void* y, const float* scale, const float* shift,
+                                 const void* residual, const float* res_scale, const float* res_shift, void* out,
+                                 uint8_t* maskbits, const void* w, void* y1, float* stats, void* stream) {
+  ProfScope _prof(PC_FUSED_FWD, stream);
+  if (d != nullptr) {
+    const ConvWork cw = conv_work(d);
+    _prof.work(3.0 * cw.in + cw.in / 16 + cw.out + 2 * cw.w, cw.flops);   // y, residual read, out + mask written; y1 written
+  }
+  if (y == nullptr || scale == nullptr || shift == nullptr || residual == nullptr || out == nullptr || maskbits == nullptr ||
+      w == nullptr || y1 == nullptr || (res_scale == nullptr) != (res_shift == nullptr))
+    return ICAMD_ERR_BAD_ARG;
+  if (!icamd_bn_apply_conv1x1_fused_supported(d)) return ICAMD_ERR_UNSUPPORTED;
+  FusedFwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.y = (const bf16_t*)y; p.res = (const bf16_t*)residual; p.scale = scale; p.shift = shift; p.res_scale = res_scale;
+  p.res_shift = res_shift; p.out = (bf16_t*)out; p.maskbits = maskbits; p.w = (const bf16_t*)w; p.y1 = (bf16_t*)y1; p.stats = stats;
+  p.M = d->N * d->OH * d->OW; p.K = d->Cin; p.N = d->Cout;
+  return icamd_bn_apply_conv1x1_fused_launch(p, (hipStream_t)stream);
 }
 
 // ---- fused backward of "pointwise convolution -> BatchNorm" (conv_fused_bwd.hip) -----------------------------------------

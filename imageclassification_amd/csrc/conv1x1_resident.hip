@@ -26,6 +26,12 @@
 
 namespace {
 
+// 16 B per lane LDS-DMA with the cache policy as a (wave-uniform) run-time choice: the builtin's policy operand is an immediate
+__device__ __forceinline__ void pw_glds16(const void* src, void* dst, bool nt) {
+  if (nt) __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst), 16, 0, 2);
+  else __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst), 16, 0, 0);
+}
+
 // KS: k-steps of 32 (K = 32*KS); NF: 16-channel fragments per wave; MF: 16-row fragments per wave; WN: waves across the
 // channels (4 / WN across the rows); ADD: addend epilogue compiled in.
 // EXT: bias, GELU epilogues, a row pitch different from K and zero-extended filter columns (K = 96 run as KS = 4).
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
+  const bool nt_loads = p.nt_loads != 0;   // once-read activation streams (one channel tile per row range): non-temporal LDS-DMA
   const int fr = lane & 15, fq = lane >> 4;
   // Workgroup -> (row range `split`, channel tile `tile_n`).  Round 4: XCD-aware.  The ntiles_n channel tiles of one row range
   // stage the SAME activation tiles; numbered consecutively (rounds 2-3) they land on ntiles_n different XCDs (dispatch is
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
         // channel of row m; a Linear layer keeps a non-finite value in its own row).  Same number of LDS-DMA instructions.
         src = (m < m_end && chunk * 8 < p.Ktrue) ? p.A + ((long long)m * p.lda + chunk * 8) : zero;
       }
-      __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, 0);
+      pw_glds16(src, smem + buf * A_BYTES + q * 1024, nt_loads);
     }
   };
   // EXT, data gradient x gelu'(z): this wave's [MF*16 rows][CW] sub-tile of z, staged ONE TILE AHEAD with the activations (round 4,
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           const int chunk = pos ^ (row & (LPRA - 1));
           const int m = mwz + row;
           const bf16_t* src = m < p.M ? p.gelu_z + ((long long)m * p.N + n0 + chunk * 8) : zero;
-          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + q * 1024), 16, 0, 0);
+          pw_glds16(src, dst + q * 1024, nt_loads);
         }
       }
     }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
             src = p.addend + ((long long)m * p.N + n0 + chunk * 8);
           }
         }
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sP + q * 1024), 16, 0, 0);
+        pw_glds16(src, sP + q * 1024, nt_loads);
       }
       if constexpr (BNR) {
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           const int chunk = pos ^ (row & (LPRA - 1));
           const int m = mw + row;
           const bf16_t* src = m < p.M ? p.bn_y + ((long long)m * p.N + n0 + chunk * 8) : zero;
-          __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(sY + q * 1024), 16, 0, 0);
+          pw_glds16(src, sY + q * 1024, nt_loads);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -417,6 +424,10 @@ int mode() {
   static const int m = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e ? atoi(e) : 1; }();
   return m;
 }
+int pw_nt() {   // ICAMD_PW_NT=1: non-temporal LDS-DMA for the activation streams of single-channel-tile launches (round 5, A/B)
+  static const int m = [] { const char* e = getenv("ICAMD_PW_NT"); return e ? atoi(e) : 0; }();
+  return m;
+}
 int xcd_order() {   // ICAMD_PW_XCD=0: the consecutive numbering of rounds 2-3 (A/B runs); off when the device does not report 8 XCDs
   static const int m = [] { const char* e = getenv("ICAMD_PW_XCD"); return (e ? atoi(e) : 1) && icamd_num_xccs() == 8; }();
   return m;
@@ -493,6 +504,7 @@ int icamd_pw_resident_bnred_launch(PwResidentParams& p, hipStream_t stream) {
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
   p.xcd_groups = xcd_order();
+  p.nt_loads = (pw_nt() && p.ntiles_n == 1) ? 1 : 0;
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (p.K == 64) hipLaunchKernelGGL((conv1x1_resident_kernel<2, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
   else if (p.K == 128) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
@@ -534,6 +546,7 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   p.rows_per_split = rows;
   S = (p.M + rows - 1) / rows;
   p.xcd_groups = xcd_order();
+  p.nt_loads = (pw_nt() && p.ntiles_n == 1) ? 1 : 0;
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (big) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 8, 4, false, 2>), grid, block, 0, stream, p);
   else if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 1>), grid, block, 0, stream, p);
@@ -584,6 +597,7 @@ int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
   }
   const int grid = S * p.ntiles_n;
   p.xcd_groups = xcd_order();
+  p.nt_loads = (pw_nt() && p.ntiles_n == 1) ? 1 : 0;
   if (c.ks == 2 && c.wn == 4) return launch<2, 4, 4, 4>(p, grid, stream);
   if (c.ks == 2) return launch<2, 4, 1, 1>(p, grid, stream);
   if (c.ks == 4) return launch<4, 4, 4, 4>(p, grid, stream);

@@ -148,8 +148,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_bn_bwd_fused_kernel(const Fuse
       const int row = byte / ROWB, pc = (byte % ROWB) >> 4;
       const int off = row * CO + ((pc ^ (dy_key(row) << 1)) << 3);
       const bool ok = m0 + row < m_end;
-      __builtin_amdgcn_global_load_lds(GPTR(ok ? gp + off : zero), LPTR(base + (j * 8 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GPTR(ok ? yp + off : zero), LPTR(base + G_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
+      if (p.nt) {   // once-read streams: non-temporal LDS-DMA (MI355X_MICROARCH.md "nt-weights"; never with two slices per range)
+        __builtin_amdgcn_global_load_lds(GPTR(ok ? gp + off : zero), LPTR(base + (j * 8 + wave) * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds(GPTR(ok ? yp + off : zero), LPTR(base + G_BYTES + (j * 8 + wave) * 1024), 16, 0, 2);
+      } else {
+        __builtin_amdgcn_global_load_lds(GPTR(ok ? gp + off : zero), LPTR(base + (j * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(ok ? yp + off : zero), LPTR(base + G_BYTES + (j * 8 + wave) * 1024), 16, 0, 0);
+      }
     }
     if (wave < 4) {
       const int byte = wave * 1024 + lane * 16;
@@ -460,6 +465,8 @@ int icamd_conv1x1_bn_bwd_fused_launch(FusedBwdParams& p, hipStream_t stream) {
   p.nslices = p.CI / FCI;
   icamd_conv1x1_bn_bwd_fused_plan(p.M, p.CI, &p.S, &p.rows_per_split);
   p.xcd_pairs = (p.S % 8 == 0 && icamd_num_xccs() == 8) ? 1 : 0;
+  static const int nt = [] { const char* e = getenv("ICAMD_FUSED_NT"); return e ? atoi(e) : 0; }();
+  p.nt = (nt && p.nslices == 1) ? 1 : 0;
   const dim3 grid((unsigned)(p.S * p.nslices)), block(512);
   if (p.CO == 256) hipLaunchKernelGGL((conv1x1_bn_bwd_fused_kernel<256>), grid, block, 0, stream, p);
   else hipLaunchKernelGGL((conv1x1_bn_bwd_fused_kernel<512>), grid, block, 0, stream, p);

@@ -93,6 +93,7 @@ struct PwResidentParams {
   FastDiv divHW, divW;   // filled by the launcher
   int rows_per_split, ntiles_n;   // filled by the launcher
   int xcd_groups;                 // filled by the launcher: XCD-aware workgroup -> (row range, channel tile) order
+  int nt_loads;                   // filled by the launcher: non-temporal LDS-DMA for the activation streams
   // "ext" launches (ConvNeXt's dim-96 Linear layers: K = 96 runs as four 32-wide k-steps, the last one against zero filter
   // columns): A rows are lda elements apart and only Ktrue of the K = 128 staged columns are real
   // "bnred" launches (residual data gradient whose output is the output gradient of the PREVIOUS block's last BatchNorm):
@@ -151,11 +152,28 @@ struct FusedBwdParams {
   float* slab;          // [S][CO][CI] partial filter gradients
   const float *mean, *invstd, *scale, *c1, *c2;   // [CO]: batch statistics, gamma * invstd, mean g, mean g * xhat
   int M, CI, CO;
-  int S, rows_per_split, nslices, xcd_pairs;      // filled by the launcher
+  int S, rows_per_split, nslices, xcd_pairs, nt;  // filled by the launcher
 };
 bool icamd_conv1x1_bn_bwd_fused_wanted(long long M, int Cin, int Cout);
 void icamd_conv1x1_bn_bwd_fused_plan(int M, int Cin, int* S, int* rows_per_split);
 int icamd_conv1x1_bn_bwd_fused_launch(FusedBwdParams& p, hipStream_t stream);
+
+// Fused forward across a bottleneck boundary (conv_fused_fwd.hip): out = relu(y * scale + shift + residual) with its mask bits, and
+// y1 = out * w^T (the next block's 1x1 convolution) with that layer's BatchNorm statistics, in one pass
+struct FusedFwdParams {
+  const bf16_t* y;        // [M][K] raw convolution output the BatchNorm normalises
+  const bf16_t* res;      // [M][K] residual: an activation, or (res_scale != nullptr) the raw shortcut convolution output
+  const float *scale, *shift, *res_scale, *res_shift;   // [K]
+  bf16_t* out;            // [M][K]
+  unsigned char* maskbits;   // [M * K / 8]: bit = [out > 0]
+  const bf16_t* w;        // [N][K] filter of the next block's conv1
+  bf16_t* y1;             // [M][N]
+  float* stats;           // optional [ceil(M / 128)][2][N]
+  int M, K, N;
+  int S, rows_per_split, nt;  // filled by the launcher
+};
+bool icamd_bn_apply_conv1x1_fused_wanted(long long M, int K, int N);
+int icamd_bn_apply_conv1x1_fused_launch(FusedFwdParams& p, hipStream_t stream);
 
 // Weight-gradient problem: dw[co][t][ci] = sum_m dy[m][co] * x[n, p*stride+r-pad, q*stride+s-pad, ci]
 struct WgradParams {

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "icamd_conv2d_dgrad_bnred_supported": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv2d_dgrad_bnred": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "icamd_bn_bwd_from_gy_partials": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_longlong, c_int, c_int, _P, c_size_t, _P]),
+    "icamd_bn_apply_conv1x1_fused_supported": (c_int, [POINTER(ConvDesc)]),
+    "icamd_bn_apply_conv1x1_fused": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "icamd_conv1x1_bn_bwd_fused_supported": (c_int, [POINTER(ConvDesc)]),
     "icamd_conv1x1_bn_bwd_fused_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "icamd_conv1x1_bn_bwd_fused": (c_int, [POINTER(ConvDesc), _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t,
@@ -189,7 +191,7 @@ def require_gpu():
 
 
 PROF_CLASSES = ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_finalize", "bn_apply", "bn_bwd", "pool", "pack", "loss",
-                "optimizer", "misc", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "elementwise", "dwconv", "conv_bn_bwd_fused")
+                "optimizer", "misc", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd", "elementwise", "dwconv", "conv_bn_bwd_fused", "bn_apply_conv_fused")
 
 
 def prof_collect(work=False):

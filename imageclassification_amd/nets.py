@@ -542,8 +542,9 @@ class ResNet(PicklableModel):
     def _gf(self, p):  # fp32 grad pointer
         return self.grad_arena.data_ptr() + 4 * p.offset
 
-    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s, maskbits=None, res_bn=None):
-        """y = conv(x); out = act(bn(y) (+ residual)). Training: batch statistics from the conv epilogue."""
+    def _conv_bn_fwd(self, ws, conv, bn, x, N, IH, IW, y, out, residual, relu, s, maskbits=None, res_bn=None, conv_launch=None):
+        """y = conv(x); out = act(bn(y) (+ residual)). Training: batch statistics from the conv epilogue.
+        conv_launch(stats_ptr): replaces the convolution launch (round 5: the fused "previous block's apply + this conv1" kernel)."""
         lib = self.lib
         d = conv.desc(N, IH, IW)
         st = self.stat_arena.data_ptr() + 4 * bn.stat_offset
@@ -552,6 +553,9 @@ class ResNet(PicklableModel):
         stem = conv is self.stem_conv
 
         def conv_fwd(stats_ptr):
+            if conv_launch is not None:
+                conv_launch(stats_ptr)
+                return
             if stem:
                 hip.check(lib.icamd_stem7x7s2_fwd(x, self._w(conv), y.data_ptr(), None, stats_ptr, 0, N, IH, IW, conv.cout_p, s),
                           conv.name)
@@ -611,10 +615,31 @@ class ResNet(PicklableModel):
                                                      s), "stem bn+relu+maxpool")
         x = ws["p0"]
         h, w = x.shape[1], x.shape[2]
-        for blk, b in zip(self.blocks, ws["blocks"]):
+        # Round 5: the final BatchNorm apply (+ shortcut + ReLU + mask) of a bottleneck block may be DEFERRED into the next block's
+        # first convolution (icamd_bn_apply_conv1x1_fused: the block output is written once and multiplied while it is in LDS instead
+        # of being re-read by that convolution); `pending` then holds what the apply needs and x is the buffer it will fill.
+        pending = None
+        nblocks = len(self.blocks)
+        for bi, (blk, b) in enumerate(zip(self.blocks, ws["blocks"])):
             b["in"] = x
             b["in_hw"] = (h, w)
             convs, bns = blk["convs"], blk["bns"]
+            first_done = False
+            if pending is not None:
+                # end of the previous block + this block's conv1 (+ statistics of its bn1) in one launch, then bn1 as usual
+                pd = pending
+                pending = None
+                c0, bn0 = convs[0], bns[0]
+                d0 = c0.desc(N, h, w)
+
+                def launch(stats_ptr, pd=pd, c0=c0, d0=d0, b=b):
+                    hip.check(lib.icamd_bn_apply_conv1x1_fused(ctypes.byref(d0), pd["y"].data_ptr(), pd["scale"], pd["shift"],
+                                                               pd["res"], pd["res_scale"], pd["res_shift"], pd["out"].data_ptr(),
+                                                               pd["mask"].data_ptr(), self._w(c0), b["y"][0].data_ptr(), stats_ptr, s),
+                              pd["name"] + " apply + " + c0.name)
+
+                self._conv_bn_fwd(ws, c0, bn0, x.data_ptr(), N, h, w, b["y"][0], b["a"][0], None, True, s, conv_launch=launch)
+                first_done = True
             res_bn = None
             if "down_conv" in blk and self.training:
                 # shortcut conv + statistics only: its BatchNorm is applied inside the block's last BatchNorm pass, the
@@ -631,10 +656,25 @@ class ResNet(PicklableModel):
             cur, ch, cw = x, h, w
             for i, (conv, bn) in enumerate(zip(convs, bns)):
                 last = i == len(convs) - 1
-                d = self._conv_bn_fwd(ws, conv, bn, cur.data_ptr(), N, ch, cw, b["y"][i], b["a"][i],
-                                      idn.data_ptr() if last else None, True, s,
-                                      b["mask"].data_ptr() if (last and self.training) else None,
-                                      res_bn if last else None)
+                if i == 0 and first_done:
+                    d = conv.desc(N, ch, cw)
+                    cur, ch, cw = b["a"][i], d.OH, d.OW
+                    continue
+                defer = False
+                if last and self.training and self.block == "bottleneck" and bi + 1 < nblocks:
+                    dn = self.blocks[bi + 1]["convs"][0].desc(N, ch, cw)
+                    defer = bool(lib.icamd_bn_apply_conv1x1_fused_supported(ctypes.byref(dn)))
+                if defer:
+                    # conv3 + statistics + finalize now; the apply pass happens inside the next block's first convolution
+                    d, sc3, sh3 = self._conv_bn_fwd(ws, conv, bn, cur.data_ptr(), N, ch, cw, b["y"][i], None, None, True, s)
+                    pending = {"y": b["y"][i], "scale": sc3, "shift": sh3, "res": idn.data_ptr(),
+                               "res_scale": res_bn[0] if res_bn else None, "res_shift": res_bn[1] if res_bn else None,
+                               "out": b["a"][i], "mask": b["mask"], "name": bn.name}
+                else:
+                    d = self._conv_bn_fwd(ws, conv, bn, cur.data_ptr(), N, ch, cw, b["y"][i], b["a"][i],
+                                          idn.data_ptr() if last else None, True, s,
+                                          b["mask"].data_ptr() if (last and self.training) else None,
+                                          res_bn if last else None)
                 cur, ch, cw = b["a"][i], d.OH, d.OW
             x, h, w = cur, ch, cw
         hip.check(lib.icamd_avgpool_fwd(x.data_ptr(), ws["pooled"].data_ptr(), N, h * w, self.feat_dim, s), "avgpool")

@@ -194,6 +194,18 @@ int icamd_bn_bwd_from_gy_partials(const float* partials, int nrows, const void* 
                                   long long rows, int C, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* Round 5: the END of one bottleneck block and the START of the next in one pass (timm Bottleneck.forward: bn3, shortcut add, act3 of
+ * block b; conv1 of block b + 1 and the statistics of its bn1 -- under model(samples), /root/reference/engine.py:48,51):
+ *   out = relu(y * scale[c] + shift[c] + residual)  (bf16 [N,IH,IW,Cin]; exactly what icamd_bn_apply / icamd_bn_apply_res_bn store,
+ *         incl. the mask bits; res_scale / res_shift != NULL: residual is the RAW shortcut convolution output, normalised on the fly),
+ *   y1  = out * w^T  (bf16 [N,OH,OW,Cout], w = [Cout][Cin] filter of the 1x1 / stride-1 convolution d), stats as icamd_conv2d_fwd's.
+ * _supported: 1 for (Cin, Cout) in {(256, 64), (256, 128), (512, 128)} with >= 16384 pixels; elsewhere the caller keeps
+ * icamd_bn_apply(_res_bn) + icamd_conv2d_fwd, which store the same bytes. */
+int icamd_bn_apply_conv1x1_fused_supported(const icamd_conv_desc* d);
+int icamd_bn_apply_conv1x1_fused(const icamd_conv_desc* d, const void* y, const float* scale, const float* shift,
+                                 const void* residual, const float* res_scale, const float* res_shift, void* out,
+                                 uint8_t* maskbits, const void* w, void* y1, float* stats, void* stream);
+
 /* Round 5: the whole backward of "1x1 convolution -> BatchNorm" at the end of a bottleneck block (timm Bottleneck.conv3 + bn3 under
  * loss.backward(), /root/reference/engine.py:64,72) in ONE pass over the 4*planes-wide tensors:
  *   c1, c2, dgamma, dbeta from the partial rows (sum g, sum g*y) an icamd_conv2d_dgrad_bnred call left (as icamd_bn_bwd_from_gy_partials),

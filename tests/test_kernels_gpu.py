@@ -1257,6 +1257,76 @@ def test_conv_dgrad_addend_maskbits(lib):
                                   hip.stream_ptr()) == 1      # bits without an addend: bad argument
 
 
+@pytest.mark.parametrize("case", [(8, 48, 48, 256, 64, False), (3, 75, 75, 256, 64, True), (3, 75, 75, 256, 128, False),
+                                  (8, 48, 48, 512, 128, True), (3, 75, 75, 512, 128, False)])
+def test_bn_apply_conv1x1_fused(lib, case):
+    """icamd_bn_apply_conv1x1_fused (round 5): the end of one bottleneck block and the start of the next in one pass -- out = relu(bn3(y3) +
+    shortcut) with its mask bits, y1 = conv1(out) of the next block with the statistics of its bn1.  `out` and the mask bits must be THE
+    BYTES icamd_bn_apply / icamd_bn_apply_res_bn store (same expression); y1 and the statistics are compared with the oracle
+    (R.bn_apply + R.conv2d_fwd) and with icamd_conv2d_fwd on the same `out`; ragged last tile; the raw-shortcut (res_bn) form; twice for
+    bit-reproducibility."""
+    hip = _hip()
+    N, H, W, K, Nout, res_bn = case
+    d = hip.conv_desc(N, H, W, K, Nout, 1, 1, 1, 0)
+    assert lib.icamd_bn_apply_conv1x1_fused_supported(ctypes.byref(d)) == 1
+    M = N * H * W
+    gen = torch.Generator().manual_seed(160)
+    y = rnd_bf16(N, H, W, K, scale=1.3, seed=161)
+    res = rnd_bf16(N, H, W, K, seed=162) if res_bn else rnd_bf16(N, H, W, K, seed=162).clamp_min(0)
+    scale, shift = 0.5 + torch.rand(K, generator=gen), torch.randn(K, generator=gen) * 0.3
+    rsc, rsh = 0.5 + torch.rand(K, generator=gen), torch.randn(K, generator=gen) * 0.3
+    w = rnd_bf16(Nout, 1, 1, K, scale=(1.0 / K) ** 0.5, seed=163)
+    residual = R.bf16_round(torch.addcmul(rsh.float(), res.float(), rsc.float())) if res_bn else res     # fma, as the kernels
+    out_ref = R.bn_apply(y, scale, shift, residual, relu=True)
+    y1_ref = R.conv2d_fwd(out_ref, w, 1, 0, None, None)
+    yd, rd, wd = to_dev_bf16(y), to_dev_bf16(res), to_dev_bf16(w)
+    scd, shd, rscd, rshd = scale.to(DEV), shift.to(DEV), rsc.to(DEV), rsh.to(DEV)
+    rows = lib.icamd_conv2d_stats_rows(ctypes.byref(d))
+    s = hip.stream_ptr()
+
+    def fused():
+        out = torch.full((N, H, W, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+        bits = torch.full((M * K // 8,), 0xAA, dtype=torch.uint8, device=DEV)
+        y1 = torch.full((N, H, W, Nout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        stats = torch.full((rows, 2, Nout), float("nan"), device=DEV)
+        rc = lib.icamd_bn_apply_conv1x1_fused(ctypes.byref(d), hip.ptr(yd), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd),
+                                              hip.ptr(rscd) if res_bn else None, hip.ptr(rshd) if res_bn else None, hip.ptr(out),
+                                              hip.ptr(bits), hip.ptr(wd), hip.ptr(y1), hip.ptr(stats), s)
+        assert rc == 0
+        sync()
+        return out, bits, y1, stats
+
+    out, bits, y1, stats = fused()
+    # the two launches it replaces
+    out2 = torch.empty_like(out)
+    bits2 = torch.empty_like(bits)
+    if res_bn:
+        assert lib.icamd_bn_apply_res_bn(hip.ptr(yd), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd), hip.ptr(rscd), hip.ptr(rshd), hip.ptr(out2),
+                                         hip.ptr(bits2), M * K, K, 1, s) == 0
+    else:
+        assert lib.icamd_bn_apply(hip.ptr(yd), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd), hip.ptr(out2), hip.ptr(bits2), M * K, K, 1, s) == 0
+    y12 = torch.empty_like(y1)
+    stats2 = torch.full((rows, 2, Nout), float("nan"), device=DEV)
+    assert lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(out2), hip.ptr(wd), hip.ptr(y12), None, None, hip.ptr(stats2), s) == 0
+    sync()
+    assert torch.equal(out, out2) and torch.equal(bits, bits2)              # the same bytes
+    got = out.float().cpu()
+    assert torch.isfinite(got).all() and R.rel_l2(got, out_ref) <= 1e-3 and R.bf16_close(got, out_ref)
+    g1 = y1.float().cpu()
+    assert torch.isfinite(g1).all() and R.rel_l2(g1, y1_ref) <= 1e-3 and R.bf16_close(g1, y1_ref)
+    assert R.max_bf16_ulp(g1, y12.float().cpu()) <= 1.0 and float((y1 != y12).float().mean()) <= 2e-2
+    # statistics = those of the values the kernel itself stored; the rows no workgroup owns are zero
+    s1, s2 = R.conv2d_stats(g1)
+    st = stats.double().cpu()
+    assert torch.isfinite(st).all()
+    assert torch.allclose(st.sum(0)[0], s1, rtol=1e-5, atol=1e-2) and torch.allclose(st.sum(0)[1], s2, rtol=1e-5, atol=1e-2)
+    out3, bits3, y13, stats3 = fused()
+    assert torch.equal(out3, out) and torch.equal(bits3, bits) and torch.equal(y13, y1) and torch.equal(stats3, stats)
+    # shapes without this form are refused (the caller keeps icamd_bn_apply + icamd_conv2d_fwd)
+    d2 = hip.conv_desc(2, 14, 14, 1024, 256, 1, 1, 1, 0)
+    assert lib.icamd_bn_apply_conv1x1_fused_supported(ctypes.byref(d2)) == 0
+
+
 @pytest.mark.parametrize("case", [(8, 48, 48, 64, 256), (3, 75, 75, 64, 256), (8, 48, 48, 128, 512), (3, 75, 75, 128, 512)])
 def test_conv1x1_bn_bwd_fused(lib, case):
     """icamd_conv1x1_bn_bwd_fused (round 5): the backward of a bottleneck's conv3 + bn3 in one pass -- BatchNorm-backward finalize
