@@ -424,8 +424,9 @@ int mode() {
   static const int m = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e ? atoi(e) : 1; }();
   return m;
 }
-int pw_nt() {   // ICAMD_PW_NT=1: non-temporal LDS-DMA for the activation streams of single-channel-tile launches (round 5, A/B)
-  static const int m = [] { const char* e = getenv("ICAMD_PW_NT"); return e ? atoi(e) : 0; }();
+int pw_nt() {   // non-temporal LDS-DMA for the activation streams of single-channel-tile launches (round 5: 17.89 -> 17.86-17.87 ms on
+                // ResNet-50, inside the noise but never worse); ICAMD_PW_NT=0: default cache policy
+  static const int m = [] { const char* e = getenv("ICAMD_PW_NT"); return e ? atoi(e) : 1; }();
   return m;
 }
 int xcd_order() {   // ICAMD_PW_XCD=0: the consecutive numbering of rounds 2-3 (A/B runs); off when the device does not report 8 XCDs

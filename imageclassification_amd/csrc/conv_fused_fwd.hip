@@ -399,7 +399,9 @@ int icamd_bn_apply_conv1x1_fused_launch(FusedFwdParams& p, hipStream_t stream) {
   rows = (rows + GTM - 1) / GTM * GTM;
   p.rows_per_split = rows;
   p.S = (p.M + rows - 1) / rows;
-  static const int nt = [] { const char* e = getenv("ICAMD_FUSED_NT"); return e ? atoi(e) : 0; }();
+  // y3 and the residual are read once: non-temporal LDS-DMA by default (ResNet-50 18.08 -> 17.89 ms together with the fused
+  // backward's, two A/B pairs on one box; ICAMD_FUSED_NT=0: default policy)
+  static const int nt = [] { const char* e = getenv("ICAMD_FUSED_NT"); return e ? atoi(e) : 1; }();
   p.nt = nt;
   const dim3 grid((unsigned)p.S), block(512);
   if (p.K == 256 && p.N == 64) hipLaunchKernelGGL((bn_apply_conv1x1_fused_kernel<256, 64>), grid, block, 0, stream, p);
