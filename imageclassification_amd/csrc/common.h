@@ -22,6 +22,18 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
 #define LPTR(p) ((void __attribute__((address_space(3)))*)(p))
 
+// Streaming loads of once-read tensors (round 5).  ICAMD_STREAM_NT (per translation unit, compile time): 1 = non-temporal.  The
+// BatchNorm passes gained 1.4 % of a ResNet-50 step from it (norm_pool.hip's own switch); tools/r5_stream_nt_variants.sh builds the
+// A/B variants of the other elementwise translation units.
+#ifndef ICAMD_STREAM_NT
+#define ICAMD_STREAM_NT 0
+#endif
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  if constexpr (ICAMD_STREAM_NT != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 // 256 B of zeros in device memory: the source of every out-of-image / out-of-range LDS-DMA lane.
 // (one zero-initialised copy per translation unit: no relocatable device code needed)
 static __device__ __attribute__((aligned(256))) unsigned int icamd_zero_page[64];

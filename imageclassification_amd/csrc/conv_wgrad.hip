@@ -688,6 +688,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_8phase_kernel(const WgradPa
 // out[i] = (accumulate ? out[i] : 0) + sum_s slab[s][i]; 16 B per lane; fixed summation order.
 // A block owns OUTS consecutive float4 outputs and splits the S slabs over 256/OUTS slab lanes (4 loads in
 // flight per thread), then folds the lanes through LDS in lane order.
+#ifndef ICAMD_SLAB_NT
+#define ICAMD_SLAB_NT 0
+#endif
+__device__ __forceinline__ f32x4 slab_ld(const f32x4* p) {
+  if constexpr (ICAMD_SLAB_NT != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
 template <int OUTS>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long n4, int S, int accumulate, int stem7_mask) {
@@ -700,12 +707,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     const f32x4* p = (const f32x4*)slab + i;
     int k = l;
     for (; k + 3 * LANES < S; k += 4 * LANES) {
-      a0 += p[(long long)k * n4];
-      a1 += p[(long long)(k + LANES) * n4];
-      a2 += p[(long long)(k + 2 * LANES) * n4];
-      a3 += p[(long long)(k + 3 * LANES) * n4];
+      a0 += slab_ld(p + (long long)k * n4);
+      a1 += slab_ld(p + (long long)(k + LANES) * n4);
+      a2 += slab_ld(p + (long long)(k + 2 * LANES) * n4);
+      a3 += slab_ld(p + (long long)(k + 3 * LANES) * n4);
     }
-    for (; k < S; k += LANES) a0 += p[(long long)k * n4];
+    for (; k < S; k += LANES) a0 += slab_ld(p + (long long)k * n4);
   }
   red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows_kernel(const bf16_t* __re
 #pragma unroll
       for (int o = 0; o < 7; ++o) {
         const unsigned int off = orow + (unsigned)o * cb;
-        const unsigned int a = *(const unsigned int*)(aB + (off < last_off ? off : last_off));
+        const unsigned int a = ld_stream((const unsigned int*)(aB + (off < last_off ? off : last_off)));
         acc[S][o] = f32x2{bf16_lo(a), bf16_hi(a)};            // (columns past W: never stored)
       }
     } else {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
       const unsigned int off = ro + (unsigned)j * cb;
-      const unsigned int v = *(const unsigned int*)(xB + (off < last_off ? off : last_off));
+      const unsigned int v = ld_stream((const unsigned int*)(xB + (off < last_off ? off : last_off)));
       nxt[j] = ((colmask >> j) & 1u) ? v : 0u;
     }
   };
@@ -332,7 +332,7 @@ __device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ 
       const unsigned int ro = dyo + (unsigned)hd * rowb;
 #pragma unroll
       for (int o = 0; o < 7; ++o) {
-        const unsigned int v = (hd >= 0 && hd < H && w0 + o < W) ? *(const unsigned int*)(dB + (ro + (unsigned)o * cb)) : 0u;
+        const unsigned int v = (hd >= 0 && hd < H && w0 + o < W) ? ld_stream((const unsigned int*)(dB + (ro + (unsigned)o * cb))) : 0u;
         dr[S][o] = f32x2{bf16_lo(v), bf16_hi(v)};
       }
     };
@@ -351,7 +351,7 @@ __device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ 
           f32x2 xu[13];
 #pragma unroll
           for (int j = 0; j < 13; ++j) {
-            const unsigned int raw = ((colmask >> j) & 1u) ? *(const unsigned int*)(xB + (ro + (unsigned)j * cb)) : 0u;
+            const unsigned int raw = ((colmask >> j) & 1u) ? ld_stream((const unsigned int*)(xB + (ro + (unsigned)j * cb))) : 0u;
             xu[j] = f32x2{bf16_lo(raw), bf16_hi(raw)};
           }
           static_for<0, NR>([&](auto rc) {
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256) void layerscale_fwd_kernel(const bf16_t* __res
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const int cg = (int)(i % cpr) * 8;
     const float k = keep != nullptr ? keep[i / vec_per_image] : 1.f;
-    const u32x4 zv = ((const u32x4*)z)[i];
-    const u32x4 iv = ((const u32x4*)inp)[i];
+    const u32x4 zv = ld_stream((const u32x4*)z + i);
+    const u32x4 iv = ld_stream((const u32x4*)inp + i);
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const bf16_t* __res
       for (long long r = r0 + rl; r < r1; r += rlanes) {
         const long long off = r * cpr + cg0 + cgi;
         const float k = keep != nullptr ? keep[r / rows_per_image] : 1.f;
-        const u32x4 dv = ((const u32x4*)dout)[off];
-        const u32x4 zv = ((const u32x4*)z)[off];
+        const u32x4 dv = ld_stream((const u32x4*)dout + off);
+        const u32x4 zv = ld_stream((const u32x4*)z + off);
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -7,6 +7,9 @@
 //   * fused AdamW + EMA over flat fp32 arenas, emitting the bf16 shadow weights the conv kernels read
 //     (reference: optimizer.step() engine.py:74 / utils.py:443, model_ema.update engine.py:68,77).
 //   * global grad-norm / clip coefficient (reference utils.py:438-442,456-468).
+// once-read streams of this translation unit use non-temporal loads (round 5: ViT-B/16 34.9-35.0 -> 34.7 ms, ResNet-50 -0.03..-0.06 ms
+// in two A/B pairs each; dwconv.hip measured worse with them and keeps the default)
+#define ICAMD_STREAM_NT 1
 #include "common.h"
 #include "icamd_internal.h"
 
@@ -229,10 +232,10 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
   const float step_size = a.lr / bc1;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 pv = ((f32x4*)p)[i];
-    f32x4 gv = ((const f32x4*)g)[i];
-    f32x4 mv = ((f32x4*)m)[i];
-    f32x4 vv = ((f32x4*)v)[i];
+    f32x4 pv = ld_stream((const f32x4*)p + i);
+    f32x4 gv = ld_stream((const f32x4*)g + i);
+    f32x4 mv = ld_stream((const f32x4*)m + i);
+    f32x4 vv = ld_stream((const f32x4*)v + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gg = gv[e] * gs;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, f
     ((f32x4*)v)[i] = vv;
     if (zero_grad & 1) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ema != nullptr) {
-      f32x4 ev = ((f32x4*)ema)[i];
+      f32x4 ev = ld_stream((const f32x4*)ema + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) ev[e] = ev[e] + a.ema_w * (pv[e] - ev[e]);
       ((f32x4*)ema)[i] = ev;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(float* __restrict__ p, f
     if (KIND == 1) ((f32x4*)v)[i] = vv;
     if (zero_grad & 1) ((f32x4*)g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ema != nullptr) {
-      f32x4 ev = ((f32x4*)ema)[i];
+      f32x4 ev = ld_stream((const f32x4*)ema + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) ev[e] = ev[e] + a.ema_w * (pv[e] - ev[e]);
       ((f32x4*)ema)[i] = ev;

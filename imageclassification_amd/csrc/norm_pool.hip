@@ -10,7 +10,22 @@
 #include <stdlib.h>
 #include <string.h>
 
+// Cache policy of the streaming 16 B loads / stores of the BatchNorm passes: bit 0 = non-temporal loads, bit 1 = non-temporal stores
+// (compile-time: the product value is set below; tools/r5_bn_nt_variants.sh builds the others for A/B runs).
+#ifndef ICAMD_BN_NT
+#define ICAMD_BN_NT 1   // round 5: non-temporal LOADS (ResNet-50 17.94-17.99 -> 17.68-17.76 ms, two A/B pairs on one box); non-temporal stores lost (18.0-18.1)
+#endif
+
 namespace {
+
+__device__ __forceinline__ u32x4 bn_ld(const void* base, long long i) {
+  if constexpr (ICAMD_BN_NT & 1) return __builtin_nontemporal_load((const u32x4*)base + i);
+  else return ((const u32x4*)base)[i];
+}
+__device__ __forceinline__ void bn_st(void* base, long long i, const u32x4 v) {
+  if constexpr (ICAMD_BN_NT & 2) __builtin_nontemporal_store(v, (u32x4*)base + i);
+  else ((u32x4*)base)[i] = v;
+}
 
 // eval-mode BN: scale/shift from the running estimates
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
   for (int e = 0; e < 8; ++e) { rsc[e] = res_bn ? res_scale[cg + e] : 1.f; rsh[e] = res_bn ? res_shift[cg + e] : 0.f; }
   for (; i < nvec; i += stride) {
-    const u32x4 v = ((const u32x4*)y)[i];
+    const u32x4 v = bn_ld(y, i);
     float f[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
       f[2 * e + 1] = fmaf(bf16_hi(v[e]), sc[2 * e + 1], sh[2 * e + 1]);
     }
     if (residual != nullptr) {
-      const u32x4 r = ((const u32x4*)residual)[i];
+      const u32x4 r = bn_ld(residual, i);
       if (res_bn) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
-    ((u32x4*)out)[i] = o;
+    bn_st(out, i, o);
     if (maskbits != nullptr) {   // bit e = [output element e > 0]: the ReLU mask the backward pass needs, 1 bit/element
       unsigned int bits = 0;
 #pragma unroll
@@ -296,8 +311,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
       for (long long r = r0 + rl; r < r1; r += rlanes) {
         const long long off = r * cpr + cg0 + cgi;
         const u32x4 d = pg.idx != nullptr ? pool_gather8(dout, pg, (unsigned)r, (unsigned)cpr, (unsigned)(cg0 + cgi))
-                                          : ((const u32x4*)dout)[off];
-        const u32x4 yv = ((const u32x4*)y)[off];
+                                          : bn_ld(dout, off);
+        const u32x4 yv = bn_ld(y, off);
         float g[8], yy[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
             for (int e = 0; e < 8; ++e)
               if (!((bits >> e) & 1u)) g[e] = 0.f;
           } else if (act != nullptr) {
-            const u32x4 a = ((const u32x4*)act)[off];
+            const u32x4 a = bn_ld(act, off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               if (!(bf16_lo(a[e]) > 0.f)) g[2 * e] = 0.f;
@@ -374,9 +389,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
       const unsigned int row = fdiv((unsigned)i, dcpr);
       d = pool_gather8(dout, pg, row, (unsigned)cpr, (unsigned)i - row * (unsigned)cpr);
     } else {
-      d = ((const u32x4*)dout)[i];
+      d = bn_ld(dout, i);
     }
-    const u32x4 yv = ((const u32x4*)y)[i];
+    const u32x4 yv = bn_ld(y, i);
     float g[8], yy[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
         for (int e = 0; e < 8; ++e)
           if (!((bits >> e) & 1u)) g[e] = 0.f;
       } else if (act != nullptr) {
-        const u32x4 a = ((const u32x4*)act)[i];
+        const u32x4 a = bn_ld(act, i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (!(bf16_lo(a[e]) > 0.f)) g[2 * e] = 0.f;
@@ -408,12 +423,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     u32x4 ov;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ov[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
-    ((u32x4*)dy)[i] = ov;
+    bn_st(dy, i, ov);
     if (gout != nullptr) {
       u32x4 gv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) gv[e] = pack_bf16x2(g[2 * e], g[2 * e + 1]);
-      ((u32x4*)gout)[i] = gv;
+      bn_st(gout, i, gv);
     }
   }
 }
@@ -452,9 +467,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_reduce_kernel(const bf16_t* _
       for (int e = 0; e < 8; ++e) { muA[e] = meanA[c + e]; isA[e] = invstdA[c + e]; muB[e] = meanB[c + e]; isB[e] = invstdB[c + e]; }
       for (long long r = r0 + rl; r < r1; r += rlanes) {
         const long long off = r * cpr + cg0 + cgi;
-        const u32x4 d = ((const u32x4*)dout)[off];
-        const u32x4 va = ((const u32x4*)yA)[off];
-        const u32x4 vb = ((const u32x4*)yB)[off];
+        const u32x4 d = bn_ld(dout, off);
+        const u32x4 va = bn_ld(yA, off);
+        const u32x4 vb = bn_ld(yB, off);
         const unsigned int bits = maskbits[off];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -509,9 +524,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(const bf16_t* __
   }
   for (; k0 < nvec; k0 += stride) {
     const long long i = reverse ? nvec - 1 - k0 : k0;
-    const u32x4 d = ((const u32x4*)dout)[i];
-    const u32x4 va = ((const u32x4*)yA)[i];
-    const u32x4 vb = ((const u32x4*)yB)[i];
+    const u32x4 d = bn_ld(dout, i);
+    const u32x4 va = bn_ld(yA, i);
+    const u32x4 vb = bn_ld(yB, i);
     const unsigned int bits = maskbits[i];
     float oa[8], ob[8];
 #pragma unroll
@@ -526,8 +541,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dual_apply_kernel(const bf16_t* __
     u32x4 pa, pb;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { pa[e] = pack_bf16x2(oa[2 * e], oa[2 * e + 1]); pb[e] = pack_bf16x2(ob[2 * e], ob[2 * e + 1]); }
-    ((u32x4*)dyA)[i] = pa;
-    ((u32x4*)dyB)[i] = pb;
+    bn_st(dyA, i, pa);
+    bn_st(dyB, i, pb);
   }
 }
 

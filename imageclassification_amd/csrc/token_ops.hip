@@ -5,6 +5,9 @@
 // Replaces what ATen runs for timm's LayerNorm / GELU / Linear-bias layers under `model(samples)` and
 // `loss.backward()` (/root/reference/engine.py:48,51,64,72; ConvNeXt block spec
 // /root/reference/semantic_segmentation/backbone/convnext.py:43-56,158-182).
+// once-read streams of this translation unit use non-temporal loads (round 5: ViT-B/16 34.9-35.0 -> 34.7 ms, ResNet-50 -0.03..-0.06 ms
+// in two A/B pairs each; dwconv.hip measured worse with them and keeps the default)
+#define ICAMD_STREAM_NT 1
 #include "common.h"
 #include "icamd_internal.h"
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
       u32x4 raw = {0u, 0u, 0u, 0u};
-      if (has[it] && live) raw = *(const u32x4*)(xr + (sub + it * LPR) * 8);
+      if (has[it] && live) raw = ld_stream((const u32x4*)(xr + (sub + it * LPR) * 8));
       unpack8(raw, v[it]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[it][e];
@@ -144,9 +147,9 @@ __global__ __launch_bounds__(256, NV == 1 ? 4 : 3) void layernorm_bwd_kernel(con
     for (int it = 0; it < NV; ++it) {
       nd[it] = u32x4{0u, 0u, 0u, 0u}; nx[it] = nd[it]; na[it] = nd[it];
       if (has[it] && live) {
-        nd[it] = *(const u32x4*)(dy + ro + (sub + it * LPR) * 8);
-        nx[it] = *(const u32x4*)(x + ro + (sub + it * LPR) * 8);
-        if (addend != nullptr) na[it] = *(const u32x4*)(addend + ro + (sub + it * LPR) * 8);
+        nd[it] = ld_stream((const u32x4*)(dy + ro + (sub + it * LPR) * 8));
+        nx[it] = ld_stream((const u32x4*)(x + ro + (sub + it * LPR) * 8));
+        if (addend != nullptr) na[it] = ld_stream((const u32x4*)(addend + ro + (sub + it * LPR) * 8));
       }
     }
   };
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, NV == 1 ? 4 : 3) void layernorm_bwd_kernel(con
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ z, bf16_t* __restrict__ a, long long nvec) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const u32x4 v = ((const u32x4*)z)[i];
+    const u32x4 v = ld_stream((const u32x4*)z + i);
     ((u32x4*)a)[i] = gelu8(v);
   }
 }
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ dz, long long nvec) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const u32x4 g = ((const u32x4*)da)[i];
-    const u32x4 v = ((const u32x4*)z)[i];
+    const u32x4 g = ld_stream((const u32x4*)da + i);
+    const u32x4 v = ld_stream((const u32x4*)z + i);
     ((u32x4*)dz)[i] = gelu_bwd8(g, v);
   }
 }
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
     if (rl < rlanes) {
       for (long long r = r0 + rl; r < r1; r += rlanes) {
-        const u32x4 v = *(const u32x4*)(x + r * ld + (cg0 + cgi) * 8);
+        const u32x4 v = ld_stream((const u32x4*)(x + r * ld + (cg0 + cgi) * 8));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s[2 * e] += bf16_lo(v[e]); s[2 * e + 1] += bf16_hi(v[e]); }
       }
