@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave % WN, wm = wave / WN;
-  const bool nt_loads = p.nt_loads != 0;   // once-read activation streams (one channel tile per row range): non-temporal LDS-DMA
+  // non-temporal LDS-DMA for the once-read streams: the activation tile when one channel tile covers a row range (bit 0), the
+  // addend / BatchNorm-input / z patches always (bit 1: a workgroup's own channels, nobody else reads them)
+  const bool nt_loads = (p.nt_loads & 1) != 0, nt_patch = (p.nt_loads & 2) != 0;
   const int fr = lane & 15, fq = lane >> 4;
   // Workgroup -> (row range `split`, channel tile `tile_n`).  Round 4: XCD-aware.  The ntiles_n channel tiles of one row range
   // stage the SAME activation tiles; numbered consecutively (rounds 2-3) they land on ntiles_n different XCDs (dispatch is
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           const int chunk = pos ^ (row & (LPRA - 1));
           const int m = mwz + row;
           const bf16_t* src = m < p.M ? p.gelu_z + ((long long)m * p.N + n0 + chunk * 8) : zero;
-          pw_glds16(src, dst + q * 1024, nt_loads);
+          pw_glds16(src, dst + q * 1024, nt_patch);
         }
       }
     }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
             src = p.addend + ((long long)m * p.N + n0 + chunk * 8);
           }
         }
-        pw_glds16(src, sP + q * 1024, nt_loads);
+        pw_glds16(src, sP + q * 1024, nt_patch);
       }
       if constexpr (BNR) {
 #pragma unroll
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
           const int chunk = pos ^ (row & (LPRA - 1));
           const int m = mw + row;
           const bf16_t* src = m < p.M ? p.bn_y + ((long long)m * p.N + n0 + chunk * 8) : zero;
-          pw_glds16(src, sY + q * 1024, nt_loads);
+          pw_glds16(src, sY + q * 1024, nt_patch);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -424,9 +426,10 @@ int mode() {
   static const int m = [] { const char* e = getenv("ICAMD_PW_RESIDENT"); return e ? atoi(e) : 1; }();
   return m;
 }
-int pw_nt() {   // non-temporal LDS-DMA for the activation streams of single-channel-tile launches (round 5: 17.89 -> 17.86-17.87 ms on
-                // ResNet-50, inside the noise but never worse); ICAMD_PW_NT=0: default cache policy
-  static const int m = [] { const char* e = getenv("ICAMD_PW_NT"); return e ? atoi(e) : 1; }();
+int pw_nt() {   // non-temporal LDS-DMA for once-read streams (round 5): 1 = the activation tile of single-channel-tile launches, 2 (default)
+                // = also the addend / BatchNorm-input / z patches of every launch (ResNet-50: 17.89 -> 17.87 ms with 1, 18.02-18.09 ->
+                // 17.96 with 2 on another box; never worse); ICAMD_PW_NT=0: default cache policy
+  static const int m = [] { const char* e = getenv("ICAMD_PW_NT"); return e ? atoi(e) : 2; }();
   return m;
 }
 int xcd_order() {   // ICAMD_PW_XCD=0: the consecutive numbering of rounds 2-3 (A/B runs); off when the device does not report 8 XCDs
@@ -505,7 +508,7 @@ int icamd_pw_resident_bnred_launch(PwResidentParams& p, hipStream_t stream) {
     p.divW = make_fastdiv((unsigned)p.sub2_w);
   }
   p.xcd_groups = xcd_order();
-  p.nt_loads = (pw_nt() && p.ntiles_n == 1) ? 1 : 0;
+  p.nt_loads = pw_nt() ? ((p.ntiles_n == 1 ? 1 : 0) | (pw_nt() >= 2 ? 2 : 0)) : 0;
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (p.K == 64) hipLaunchKernelGGL((conv1x1_resident_kernel<2, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
   else if (p.K == 128) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 4, 2, 4, true, false, true>), grid, block, 0, stream, p);
@@ -547,7 +550,7 @@ int icamd_pw_resident_ext_launch(PwResidentParams& p, hipStream_t stream) {
   p.rows_per_split = rows;
   S = (p.M + rows - 1) / rows;
   p.xcd_groups = xcd_order();
-  p.nt_loads = (pw_nt() && p.ntiles_n == 1) ? 1 : 0;
+  p.nt_loads = pw_nt() ? ((p.ntiles_n == 1 ? 1 : 0) | (pw_nt() >= 2 ? 2 : 0)) : 0;
   const dim3 grid((unsigned)(S * p.ntiles_n)), block(256);
   if (big) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 8, 4, false, 2>), grid, block, 0, stream, p);
   else if (k96) hipLaunchKernelGGL((conv1x1_resident_kernel<4, 2, 4, 4, false, 1>), grid, block, 0, stream, p);
@@ -598,7 +601,7 @@ int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
   }
   const int grid = S * p.ntiles_n;
   p.xcd_groups = xcd_order();
-  p.nt_loads = (pw_nt() && p.ntiles_n == 1) ? 1 : 0;
+  p.nt_loads = pw_nt() ? ((p.ntiles_n == 1 ? 1 : 0) | (pw_nt() >= 2 ? 2 : 0)) : 0;
   if (c.ks == 2 && c.wn == 4) return launch<2, 4, 4, 4>(p, grid, stream);
   if (c.ks == 2) return launch<2, 4, 1, 1>(p, grid, stream);
   if (c.ks == 4) return launch<4, 4, 4, 4>(p, grid, stream);

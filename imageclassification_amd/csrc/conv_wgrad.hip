@@ -689,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_8phase_kernel(const WgradPa
 // A block owns OUTS consecutive float4 outputs and splits the S slabs over 256/OUTS slab lanes (4 loads in
 // flight per thread), then folds the lanes through LDS in lane order.
 #ifndef ICAMD_SLAB_NT
-#define ICAMD_SLAB_NT 0
+#define ICAMD_SLAB_NT 1   // round 5: the slab fold reads every slab once (ResNet-50 18.02-18.09 -> 17.93-17.94 ms, two A/B pairs)
 #endif
 __device__ __forceinline__ f32x4 slab_ld(const f32x4* p) {
   if constexpr (ICAMD_SLAB_NT != 0) return __builtin_nontemporal_load(p);
