@@ -1735,7 +1735,7 @@ def test_layernorm_bwd_bits_do_not_depend_on_a_second_stream(lib):
 
 
 @pytest.mark.parametrize("which", ["layernorm_bwd_c96", "layernorm_bwd_c384", "layernorm_bwd_c768", "layerscale_bwd", "colsum_rows",
-                                   "dwconv7_wgrad"])
+                                   "dwconv7_wgrad", "bn_apply_conv_fused_stats", "conv_bn_bwd_fused"])
 def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
     """The other kernels that carry per-thread sums through a row loop with a divergent store section (the pattern behind
     test_layernorm_bwd_bits_do_not_depend_on_a_second_stream), at the sizes the models call them with: alone and next to a ring
@@ -1794,6 +1794,63 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
         def run():
             assert lib.icamd_colsum_rows(hip.ptr(x), rows, C, C, hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, main.cuda_stream) == 0
         oracle = {0: (x.float().cpu().double().sum(0).float(), 1e-5)}
+    elif which == "bn_apply_conv_fused_stats":
+        # round 5: the fused block-boundary forward keeps the BatchNorm statistics of y1 as packed f32 pairs per lane across its tile
+        # loop (conv_fused_fwd.hip store_y1); model size of layer1 (256 -> 64 at 56 x 56, batch 64)
+        K, Nout, rows = 256, 64, 64 * 56 * 56
+        df = hip.conv_desc(64, 56, 56, K, Nout, 1, 1, 1, 0)
+        y = (torch.randn(rows, K, device=DEV, generator=g) * 1.3).bfloat16()
+        res = torch.randn(rows, K, device=DEV, generator=g).clamp_min(0).bfloat16()
+        wq = (torch.randn(Nout, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+        sc, sh = 0.5 + torch.rand(K, device=DEV, generator=g), torch.randn(K, device=DEV, generator=g) * 0.3
+        nrows = lib.icamd_conv2d_stats_rows(ctypes.byref(df))
+        outs = [torch.empty(rows, K, dtype=torch.bfloat16, device=DEV), torch.empty(rows * K // 8, dtype=torch.uint8, device=DEV),
+                torch.empty(rows, Nout, dtype=torch.bfloat16, device=DEV), torch.empty(nrows, 2, Nout, device=DEV)]
+
+        def run():
+            assert lib.icamd_bn_apply_conv1x1_fused(ctypes.byref(df), hip.ptr(y), hip.ptr(sc), hip.ptr(sh), hip.ptr(res), None, None,
+                                                    hip.ptr(outs[0]), hip.ptr(outs[1]), hip.ptr(wq), hip.ptr(outs[2]), hip.ptr(outs[3]),
+                                                    main.cuda_stream) == 0
+        run()
+        sync()
+        y1 = outs[2].float().cpu().double()
+        oracle = {3: (torch.stack([y1.sum(0), (y1 * y1).sum(0)]).float(), 1e-5)}     # sums of the values the kernel stored
+        # (the table itself is compared bit for bit between runs; against the oracle its SUM over the partial rows)
+    elif which == "conv_bn_bwd_fused":
+        # round 5: the fused conv3 + bn3 backward (MFMA accumulators only, but its transform is scalar fp32 code the SLP vectoriser
+        # may pack): bit-stable next to the ring weight gradient, sums against the three launches' values
+        Ci, Co, rows = 64, 256, 64 * 56 * 56
+        df = hip.conv_desc(64, 56, 56, Ci, Co, 1, 1, 1, 0)
+        gq = (torch.randn(rows, Co, device=DEV, generator=g) * (torch.rand(rows, Co, device=DEV, generator=g) > 0.5)).bfloat16()
+        yq = (torch.randn(rows, Co, device=DEV, generator=g) * 1.5 + 0.3).bfloat16()
+        xq = torch.randn(rows, Ci, device=DEV, generator=g).clamp_min(0).bfloat16()
+        wt = (torch.randn(Ci, Co, device=DEV, generator=g) * Ci ** -0.5).bfloat16()
+        mean, var = yq.float().mean(0), yq.float().var(0, unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        scale = (0.5 + torch.rand(Co, device=DEV, generator=g)) * invstd
+        b2b = lib.icamd_bn_bwd_workspace_bytes(rows, Co)
+        b2 = torch.zeros(b2b, dtype=torch.uint8, device=DEV)
+        fwb = lib.icamd_conv1x1_bn_bwd_fused_workspace_bytes(ctypes.byref(df))
+        fw = torch.empty(fwb, dtype=torch.uint8, device=DEV)
+        outs = [torch.empty(rows, Ci, dtype=torch.bfloat16, device=DEV), torch.empty(Co, Ci, device=DEV), torch.empty(Co, device=DEV),
+                torch.empty(Co, device=DEV)]
+
+        def run():
+            assert lib.icamd_conv1x1_bn_bwd_fused(ctypes.byref(df), None, 0, hip.ptr(gq), hip.ptr(yq), hip.ptr(mean), hip.ptr(invstd),
+                                                  hip.ptr(scale), hip.ptr(outs[2]), hip.ptr(outs[3]), hip.ptr(xq), hip.ptr(wt),
+                                                  hip.ptr(outs[0]), hip.ptr(outs[1]), 0, hip.ptr(b2), b2b, hip.ptr(fw), fwb,
+                                                  main.cuda_stream) == 0
+        # the three launches on the same inputs: dgamma / dbeta bit for bit (same reduce + finalize), dw to fp32 noise
+        dy3 = torch.empty_like(gq)
+        dg3, db3 = torch.empty(Co, device=DEV), torch.empty(Co, device=DEV)
+        assert lib.icamd_bn_bwd(hip.ptr(gq), None, hip.ptr(yq), hip.ptr(mean), hip.ptr(invstd), hip.ptr(scale), hip.ptr(scale), hip.ptr(dg3),
+                                hip.ptr(db3), hip.ptr(dy3), None, None, rows, Co, 0, 0, hip.ptr(b2), b2b, main.cuda_stream) == 0
+        w3b = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(df))
+        w3 = torch.empty(w3b, dtype=torch.uint8, device=DEV)
+        dw3 = torch.empty(Co, Ci, device=DEV)
+        assert lib.icamd_conv2d_wgrad(ctypes.byref(df), hip.ptr(xq), hip.ptr(dy3), hip.ptr(dw3), 0, hip.ptr(w3), w3b, main.cuda_stream) == 0
+        sync()
+        oracle = {1: (dw3.cpu(), 1e-5), 2: (dg3.cpu(), 1e-6), 3: (db3.cpu(), 1e-6)}
     else:
         N, H, W, C = 128, 28, 28, 192
         x = torch.randn(N, H, W, C, device=DEV, generator=g).bfloat16()
@@ -1823,7 +1880,8 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
                 assert torch.equal(o, r), (which, with_side)
             # round 4: the sums themselves against the oracle at model size, second stream busy or not
             for i, (want, tol) in oracle.items():
-                assert R.rel_l2(outs[i].cpu().reshape(want.shape), want) <= tol, (which, with_side, i)
+                got_i = outs[i].double().sum(0).float().cpu() if which == "bn_apply_conv_fused_stats" else outs[i].cpu()
+                assert R.rel_l2(got_i.reshape(want.shape), want) <= tol, (which, with_side, i)
 
 
 @pytest.mark.parametrize("shape", [(2, 14, 14, 96), (3, 7, 7, 768), (2, 20, 9, 192), (1, 56, 56, 96), (3, 28, 28, 64),
