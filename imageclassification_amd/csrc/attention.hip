@@ -33,6 +33,9 @@
 // 302.  I.e. the kernels move their 225 KB per head at 3.1 TB/s -- every CU asks for its next head at the same moment and
 // then computes -- and arithmetic is not what bounds them: the next step is ONE backward kernel (q, k, v, dO, O read once:
 // 125 KB per head), not a faster pair loop.
+#ifndef ICAMD_ATTN_NT
+#define ICAMD_ATTN_NT 0   // cache policy of the once-read LDS-DMA streams of this unit: 0 default, 2 non-temporal (round 5 A/B)
+#endif
 #include "common.h"
 #include "icamd_internal.h"
 
@@ -152,8 +155,8 @@ __device__ __forceinline__ void stage_two_dma(const bf16_t* __restrict__ src0, l
     const bool ok = r < T;
     const void* a0 = ok ? (const void*)(src0 + (long long)r * ld0 + ch * 8) : (const void*)zero;
     const void* a1 = ok ? (const void*)(src1 + (long long)r * ld1 + ch * 8) : (const void*)zero;
-    __builtin_amdgcn_global_load_lds(GPTR(a0), LPTR(img0 + j * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(GPTR(a1), LPTR(img1 + j * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GPTR(a0), LPTR(img0 + j * 1024), 16, 0, ICAMD_ATTN_NT);
+    __builtin_amdgcn_global_load_lds(GPTR(a1), LPTR(img1 + j * 1024), 16, 0, ICAMD_ATTN_NT);
   }
 }
 

@@ -22,6 +22,9 @@
 // Epilogue as conv_igemm.hip: lanes own 4 consecutive channels of a pixel, bias added in fp32, one rounding, bf16 tile
 // through LDS, 16 B coalesced row stores, optional ReLU, optional per-channel sum / sum-of-squares of the rounded outputs
 // as one partial row per tile (BatchNorm statistics, no float atomics).
+#ifndef ICAMD_C64_NT
+#define ICAMD_C64_NT 0   // cache policy of the once-read LDS-DMA streams of this unit: 0 default, 2 non-temporal (round 5 A/B)
+#endif
 #include "common.h"
 #include "icamd_internal.h"
 #include <cstdlib>
@@ -353,14 +356,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_resident_kernel(const Halo
       for (int j = 0; j < LA; ++j) {
         const bf16_t* src = src0 + j * (32 * 64);
         if (j == LA - 1) src = a_zero_lane ? zero : src;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + (j * 4 + wave) * 1024), 16, 0, ICAMD_C64_NT);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < LA; ++j) {
         const int pix = pix0 + j * 32;
         const bf16_t* src = (pix >= 0 && pix < p.M && !(j == LA - 1 && a_zero_lane)) ? src0 + j * (32 * 64) : zero;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(dst + (j * 4 + wave) * 1024), 16, 0, ICAMD_C64_NT);
       }
     }
   };

@@ -15,6 +15,9 @@
 //     swizzle -- at ONE per-lane base address plus an immediate offset (buffer, r, fragment);
 //   * four waves = 2 output rows x 2 channel halves; wave-private epilogue through two 16-row LDS patches; BatchNorm
 //     partial sums in registers across tiles, one partial row per workgroup.
+#ifndef ICAMD_STEM_NT
+#define ICAMD_STEM_NT 0   // cache policy of the once-read LDS-DMA streams of this unit: 0 default, 2 non-temporal (round 5 A/B)
+#endif
 #include "common.h"
 #include "icamd_internal.h"
 #include <cstdlib>
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7s2_resident_kernel(const StemPa
         const int row = byte / PITCH;             // 0..8 (9 and up: the rounding tail, never read)
         const int ih = ih0 + row;
         const bf16_t* src = (row < A_ROWS && (unsigned)ih < (unsigned)H) ? base + (byte >> 1) : zero;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * A_BYTES + q * 1024), 16, 0, ICAMD_STEM_NT);
       }
     }
   };
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void stem7x7s2_wgrad_resident_kernel(const 
         const int row = byte / PITCH;
         const int ih = ih0 + row;
         const bf16_t* src = (row < A_ROWS && (unsigned)ih < (unsigned)H) ? xb + (byte >> 1) : zero;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * X_BYTES + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(smem + buf * X_BYTES + q * 1024), 16, 0, ICAMD_STEM_NT);
       }
     }
     const bf16_t* yb = p.dy + (((long long)n * OH + oh0) * OW) * 64;     // two output rows: TPX contiguous pixels
@@ -252,8 +255,7 @@ __global__ __launch_bounds__(512, 2) void stem7x7s2_wgrad_resident_kernel(const 
         const int row = q * 8 + (lane >> 3);      // pixel of the tile
         const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
         const int chunk = ((((lane & 7) >> 1) ^ key) << 1) | (lane & 1);
-        __builtin_amdgcn_global_load_lds(GPTR(yb + row * 64 + chunk * 8), LPTR(smem + YBASE + buf * Y_BYTES + q * 1024), 16, 0,
-                                         0);
+        __builtin_amdgcn_global_load_lds(GPTR(yb + row * 64 + chunk * 8), LPTR(smem + YBASE + buf * Y_BYTES + q * 1024), 16, 0, ICAMD_STEM_NT);
       }
     }
   };

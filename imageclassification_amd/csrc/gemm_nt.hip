@@ -541,7 +541,8 @@ bool icamd_gemm_nt_wanted(long long M, int N, int K) {
   // one per CU, sixteen K tiles each: 38.7 -> 30.6 us and 37.5 -> 29.5 us against the resident-filter kernel)
   static const bool k1024 = [] { const char* e = getenv("ICAMD_GEMM_K1024"); return !(e && atoi(e) == 0); }();
   if (k1024 && K == 1024 && N == 256 && pairs >= 160 && pairs <= 256) return true;
-  return K >= 768 && N >= 256 && (pairs >= 256 || (K >= 2048 && pairs >= 96));
+  static const int mink = [] { const char* e = getenv("ICAMD_GEMM_MINK"); return e ? atoi(e) : 768; }();   // (A/B: 384 = ConvNeXt-T stage 2's fc1)
+  return K >= mink && N >= 256 && (pairs >= 256 || (K >= 2048 && pairs >= 96));
 }
 
 int icamd_gemm_nt_launch(GemmNtParams& p, hipStream_t stream) {
