@@ -22,6 +22,9 @@ from .checkpoint import PicklableModel
 from .vit import _P, _align
 
 LN_EPS = 1e-6
+# Round 5: the layer scale (and timm drop_path's 1 / keep_prob) folded into fc2's filter and bias, the residual added in fc2's store
+# pass (icamd_layerscale_fold; DESIGN.md section 5, round-5 finding 10).  0: fc2 -> icamd_layerscale_fwd / _bwd as in rounds 2-4.
+_FUSED_LS = os.environ.get("ICAMD_FUSED_LAYERSCALE", "1") != "0"
 
 CONFIGS = {
     "convnext_tiny": ((3, 3, 9, 3), (96, 192, 384, 768)),
@@ -149,6 +152,17 @@ class ConvNeXt(PicklableModel):
         self._tr_ntjobs = len(tjobs)
         self._tr_jobs = torch.tensor(jobs if jobs else [[0, 0]], dtype=torch.int32, device=dev)
         self._tr_njobs = len(jobs)
+        # folded layer scale: one folded fc2 bias per block; the folded filter takes fc2's place in the bf16 shadow (and, through
+        # refresh_transposed, in the transposed shadow), so _w(fc2) / _wt(fc2) are the folded operands
+        self.fused_ls = _FUSED_LS
+        fb = 0
+        for st in self.stages:
+            for blk in st["blocks"]:
+                blk["fb_off"] = fb
+                fb = _align(fb + blk["fc2"].cout_p, 64)
+        self.fold_bias = torch.zeros(max(fb, 64), dtype=torch.float32, device=dev)
+        self._ls_cbs = None          # the per-block constants the shadow is currently folded with
+        self._ls_jobs = None
 
     def _ctor_kwargs(self):
         return {"arch": self.arch, "num_classes": self.num_classes, "drop_path_rate": self.drop_path_rate}
@@ -225,8 +239,41 @@ class ConvNeXt(PicklableModel):
                                              hip.stream_ptr()), "f32_to_bf16")
         self.refresh_transposed()
 
+    def _ls_mode_cbs(self):
+        """timm drop_path scales the kept samples by 1 / keep_prob in training; identity in eval."""
+        blocks = [blk for st in self.stages for blk in st["blocks"]]
+        if self.training and self.injected_keep is not None:      # tests: the scale is whatever the injected masks carry
+            cbs = []
+            for blk, k in zip(blocks, self.injected_keep):
+                k = k.float().cpu()
+                cb = float(k.max()) if float(k.max()) > 0.0 else 1.0
+                assert bool(((k == 0) | (k == cb)).all()), "folded layer scale: a keep mask is {0, c} per block"
+                cbs.append(cb if blk["rate"] > 0.0 else 1.0)
+            return cbs
+        return [1.0 / (1.0 - blk["rate"]) if (self.training and blk["rate"] > 0.0) else 1.0 for blk in blocks]
+
+    def _fold_layerscale(self):
+        import struct
+        cbs = self._ls_mode_cbs()
+        if self._ls_jobs is None or cbs != self._ls_cbs:
+            rows, row0, elems = [], 0, 0
+            blocks = [blk for st in self.stages for blk in st["blocks"]]
+            for blk, cb in zip(blocks, cbs):
+                c = blk["fc2"]
+                bits = struct.unpack("<i", struct.pack("<f", cb))[0]
+                rows.append([c.w.offset, blk["gamma"].offset, c.b.offset, blk["fb_off"], c.cout, c.cin, row0, bits])
+                row0 += c.cout
+                elems += c.cout * c.cin
+            self._ls_jobs = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            self._ls_rows, self._ls_elems, self._ls_cbs = row0, elems, cbs
+        hip.check(self.lib.icamd_layerscale_fold(self.param_arena.data_ptr(), self.shadow.data_ptr(), self.fold_bias.data_ptr(),
+                                                 self._ls_jobs.data_ptr(), self._ls_jobs.shape[0], self._ls_rows, self._ls_elems,
+                                                 hip.stream_ptr()), "layer scale fold")
+
     def refresh_transposed(self):
         s = hip.stream_ptr()
+        if self.fused_ls:
+            self._fold_layerscale()      # before the transposes: fc2's slot of the shadow becomes the folded filter
         if self._tr_ntjobs:
             hip.check(self.lib.icamd_filter_transpose_tiled(self.shadow.data_ptr(), self.shadow_t.data_ptr(),
                                                             self._tr_descs.data_ptr(), self._tr_tjobs.data_ptr(),
@@ -284,7 +331,7 @@ class ConvNeXt(PicklableModel):
             rows = N * h * w
             for blk in st["blocks"]:
                 sw["blocks"].append({"d": act(N, h, w, dim), "h": act(N, h, w, dim), "z1": act(N, h, w, 4 * dim),
-                                     "a": act(N, h, w, 4 * dim), "z2": act(N, h, w, dim), "out": act(N, h, w, dim),
+                                     "a": act(N, h, w, 4 * dim), "z2": None if self.fused_ls else act(N, h, w, dim), "out": act(N, h, w, dim),
                                      "st": f32(2 * rows), "keep": None})
                 wg = max(wg, lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(blk["fc1"].desc(N, h, w))),
                          lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(blk["fc2"].desc(N, h, w))))
@@ -313,6 +360,11 @@ class ConvNeXt(PicklableModel):
                              lib.icamd_layerscale_bwd_workspace_bytes(max_rows, max(self.dims)))
         ws["cs_ws"] = torch.zeros(ws["cs_bytes"], dtype=torch.uint8, device=dev)
         ws["max_act"] = max_act
+        if self.fused_ls:     # side-lane scratch of the folded layer's parameter gradients
+            dmax = max(self.dims)
+            ws["ls_G"] = f32(4 * dmax * dmax)
+            ws["ls_S"] = f32(dmax)
+            ws["ls_drop"] = f32(N * dmax)
         self._ws[key] = ws
         return ws
 
@@ -387,6 +439,8 @@ class ConvNeXt(PicklableModel):
                 ws["keep_copied"][slot] = torch.cuda.Event()
                 ws["keep_copied"][slot].record()
                 drop_rows = ws["keep_dev"]
+        if self.fused_ls and self._ls_cbs != self._ls_mode_cbs():
+            self.refresh_transposed()     # train() <-> eval(), or a test's injected masks: fold with this mode's constants
         for si, (st, sw) in enumerate(zip(self.stages, ws["stages"])):
             dim = st["dim"]
             if si > 0:
@@ -404,7 +458,6 @@ class ConvNeXt(PicklableModel):
                 c1 = blk["fc1"]                                                   # z1 = pwconv1(h), a = gelu(z1): one kernel
                 hip.check(lib.icamd_conv2d_fwd_gelu(ctypes.byref(c1.desc(N, h, w)), b["h"].data_ptr(), self._w(c1),
                                                     (None if logits_only else b["z1"].data_ptr()), b["a"].data_ptr(), self._pf(c1.b), s), c1.name + " + gelu")
-                self._conv(blk["fc2"], b["a"].data_ptr(), b["z2"], N, h, w, s)
                 keep = None
                 if self.training and blk["rate"] > 0.0:
                     if self.injected_keep is not None:
@@ -412,9 +465,21 @@ class ConvNeXt(PicklableModel):
                     else:
                         keep = drop_rows[bi]
                 b["keep"] = keep
-                hip.check(lib.icamd_layerscale_fwd(b["z2"].data_ptr(), x.data_ptr(), self._pf(blk["gamma"]),
-                                                   None if keep is None else keep.data_ptr(), b["out"].data_ptr(), rows, dim,
-                                                   h * w, s), "layer scale")
+                if self.fused_ls:
+                    # out = x + a W2'^T + b2' in fc2's store pass; the dropped samples: out = x, and their rows of `a` are cleared
+                    # so that they vanish from fc2's weight gradient (which then runs on the unmasked output gradient)
+                    c2 = blk["fc2"]
+                    hip.check(lib.icamd_conv2d_fwd(ctypes.byref(c2.desc(N, h, w)), b["a"].data_ptr(), self._w(c2),
+                                                   b["out"].data_ptr(), self.fold_bias.data_ptr() + 4 * blk["fb_off"],
+                                                   x.data_ptr(), None, s), c2.name + " + layer scale + residual")
+                    if keep is not None:
+                        hip.check(lib.icamd_rows_fix(keep.data_ptr(), N, b["out"].data_ptr(), x.data_ptr(), h * w * dim * 2,
+                                                     None if logits_only else b["a"].data_ptr(), h * w * dim * 8, s), "drop path")
+                else:
+                    self._conv(blk["fc2"], b["a"].data_ptr(), b["z2"], N, h, w, s)
+                    hip.check(lib.icamd_layerscale_fwd(b["z2"].data_ptr(), x.data_ptr(), self._pf(blk["gamma"]),
+                                                       None if keep is None else keep.data_ptr(), b["out"].data_ptr(), rows, dim,
+                                                       h * w, s), "layer scale")
                 x = b["out"]
                 bi += 1
         dl = self.dims[-1]
@@ -479,15 +544,41 @@ class ConvNeXt(PicklableModel):
         if hook:
             hook(self.head_nw.offset, self.n_params, lane.events())
         other = G[3]
+        nblocks, bj = sum(self.depths), 0     # bj: blocks done, counted from the last one
         for si in range(len(self.stages) - 1, -1, -1):
             st, sw = self.stages[si], ws["stages"][si]
             dim = st["dim"]
             rows = N * h * w
             for blk, b in zip(reversed(st["blocks"]), reversed(sw["blocks"])):
                 keep = None if b["keep"] is None else b["keep"].data_ptr()
-                hip.check(lib.icamd_layerscale_bwd(dout, b["z2"].data_ptr(), self._pf(blk["gamma"]), keep, W(G[1]),
-                                                   self._gf(blk["gamma"]), rows, dim, h * w, acc, csp, csb, s), "layer scale bwd")
-                gemm_bwd(blk["fc2"], b["a"].data_ptr(), G[1], N, h, w, G[4], gelu_z=b["z1"].data_ptr())   # G4 = d z1
+                if self.fused_ls:
+                    # fc2 with the layer scale folded in: its data gradient reads the block's output gradient itself (the folded,
+                    # transposed filter carries cb * gamma); the side lane forms G = dout^T a and the column sums of dout over the
+                    # kept samples, and from them the gradients of W2, b2 and gamma (icamd_layerscale_param_grads)
+                    c2, gam = blk["fc2"], blk["gamma"]
+                    d2 = c2.desc(N, h, w)
+                    cb = self._ls_cbs[nblocks - 1 - bj]
+                    lsG, lsS, lsD = ws["ls_G"].data_ptr(), ws["ls_S"].data_ptr(), ws["ls_drop"].data_ptr()
+
+                    def side(st_, d2=d2, c2=c2, gam=gam, cb=cb, keep=keep, a_ptr=b["a"].data_ptr(), dout=dout, hw=h * w, dim=dim):
+                        if keep is not None:
+                            hip.check(lib.icamd_dropped_colsum(dout, keep, N, hw, dim, lsD, st_), "dropped column sums")
+                        hip.check(lib.icamd_conv2d_wgrad_bias(ctypes.byref(d2), a_ptr, dout, lsG, lsS, 0, wsp, wsb, st_),
+                                  c2.name + " wgrad+bias (folded)")
+                        hip.check(lib.icamd_layerscale_param_grads(lsG, self._pf(c2.w), self._pf(c2.b), self._pf(gam), lsS,
+                                                                   None if keep is None else lsD, N, cb, c2.cout, c2.cin,
+                                                                   self._gf(c2.w), self._gf(c2.b), self._gf(gam), acc, st_),
+                                  "layer scale parameter gradients")
+                    lane.launch(side, reads=(dout,))
+                    hip.check(lib.icamd_conv2d_dgrad_gelu(ctypes.byref(d2), dout, self._wt(c2), b["z1"].data_ptr(), W(G[4]), s),
+                              c2.name + " dgrad + gelu bwd (folded)")
+                    if keep is not None:
+                        hip.check(lib.icamd_rows_fix(keep, N, G[4], None, h * w * dim * 8, None, 0, s), "drop path bwd")
+                    bj += 1
+                else:
+                    hip.check(lib.icamd_layerscale_bwd(dout, b["z2"].data_ptr(), self._pf(blk["gamma"]), keep, W(G[1]),
+                                                       self._gf(blk["gamma"]), rows, dim, h * w, acc, csp, csb, s), "layer scale bwd")
+                    gemm_bwd(blk["fc2"], b["a"].data_ptr(), G[1], N, h, w, G[4], gelu_z=b["z1"].data_ptr())   # G4 = d z1
                 gemm_bwd(blk["fc1"], b["h"].data_ptr(), G[4], N, h, w, G[1])                 # G1 = d h
                 ln_bwd(G[1], b["d"], b["st"], blk["nw"], blk["nb"], G[2], rows, dim)         # G2 = d (dwconv out)
                 bin_ptr, g2, hh, ww_, dd = b["in"].data_ptr(), G[2], h, w, dim

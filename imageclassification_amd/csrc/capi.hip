@@ -94,6 +94,15 @@ int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, f
 int icamd_layerscale_fwd_launch(const bf16_t* z, const bf16_t* inp, const float* gamma, const float* keep, bf16_t* out,
                                 long long rows, int C, long long rows_per_image, hipStream_t s);
 int icamd_layerscale_bwd_blocks(long long rows);
+int icamd_layerscale_fold_launch(const float* params, bf16_t* shadow, float* fold_bias, const long long* jobs, int njobs,
+                                 int total_rows, hipStream_t s);
+int icamd_rows_fix_launch(const float* keep, int n_images, void* dst1, const void* src1, long long bytes1, void* dst2,
+                          long long bytes2, hipStream_t s);
+int icamd_dropped_colsum_launch(const bf16_t* dy, const float* keep, int n_images, long long rows_per_image, int C, float* partial,
+                                hipStream_t s);
+int icamd_layerscale_param_grads_launch(const float* G, const float* w, const float* bias, const float* gamma,
+                                        const float* colsum_all, const float* dropped, int n_images, float cb, int C, int K,
+                                        float* dw, float* dbias, float* dgamma, int accumulate, hipStream_t s);
 int icamd_layerscale_bwd_launch(const bf16_t* dout, const bf16_t* z, const float* gamma, const float* keep, bf16_t* dz,
                                 float* part, long long rows, int C, long long rows_per_image, hipStream_t s);
 int icamd_filter_transpose_tiled_launch(const bf16_t* src_base, bf16_t* dst_base, const long long* descs, const int* jobs,
@@ -977,6 +986,47 @@ int icamd_layerscale_bwd(const void* dout, const void* z, const float* gamma, co
                                        rows_per_image, (hipStream_t)stream);
   if (rc) return rc;
   return icamd_sum_partials_launch(part, nblk, C, dgamma, scratch, accumulate, chunks, scratch + C, (hipStream_t)stream);
+}
+
+// Layer scale folded into the Mlp's second Linear layer (round 5): see include/icamd.h
+int icamd_layerscale_fold(const float* params, void* shadow, float* fold_bias, const long long* jobs, int njobs, int total_rows,
+                          long long total_elements, void* stream) {
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(6.0 * (double)total_elements);
+  if (params == nullptr || shadow == nullptr || fold_bias == nullptr || jobs == nullptr || njobs <= 0 || total_rows <= 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_layerscale_fold_launch(params, (bf16_t*)shadow, fold_bias, jobs, njobs, total_rows, (hipStream_t)stream);
+}
+
+int icamd_rows_fix(const float* keep, int n_images, void* dst1, const void* src1, long long bytes1, void* dst2, long long bytes2,
+                   void* stream) {
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(4.0 * n_images);   // (the bytes of the dropped samples are data-dependent: not booked)
+  if (keep == nullptr || n_images <= 0 || n_images > 65535 || (dst1 == nullptr && dst2 == nullptr) || bytes1 < 0 || bytes2 < 0 ||
+      bytes1 % 16 != 0 || bytes2 % 16 != 0 || (dst1 == nullptr && src1 != nullptr))
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_rows_fix_launch(keep, n_images, dst1, src1, bytes1, dst2, bytes2, (hipStream_t)stream);
+}
+
+int icamd_dropped_colsum(const void* dy, const float* keep, int n_images, long long rows_per_image, int C, float* partial,
+                         void* stream) {
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work(4.0 * n_images * C);
+  if (dy == nullptr || keep == nullptr || partial == nullptr || n_images <= 0 || rows_per_image <= 0 || C <= 0 || C % 8 != 0)
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_dropped_colsum_launch((const bf16_t*)dy, keep, n_images, rows_per_image, C, partial, (hipStream_t)stream);
+}
+
+int icamd_layerscale_param_grads(const float* G, const float* w, const float* bias, const float* gamma, const float* colsum_all,
+                                 const float* dropped, int n_images, float cb, int C, int K, float* dw, float* dbias,
+                                 float* dgamma, int accumulate, void* stream) {
+  ProfScope _prof(PC_ELEMWISE, stream);
+  _prof.work((accumulate ? 16.0 : 12.0) * C * K);
+  if (G == nullptr || w == nullptr || bias == nullptr || gamma == nullptr || colsum_all == nullptr || dw == nullptr ||
+      dbias == nullptr || dgamma == nullptr || C <= 0 || K <= 0 || K % 4 != 0 || (dropped != nullptr && n_images <= 0))
+    return ICAMD_ERR_BAD_ARG;
+  return icamd_layerscale_param_grads_launch(G, w, bias, gamma, colsum_all, dropped, n_images, cb, C, K, dw, dbias, dgamma,
+                                             accumulate, (hipStream_t)stream);
 }
 
 // ---- attention (ViT) --------------------------------------------------------------------------------------------

@@ -584,6 +584,129 @@ int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, f
   return icamd_slab_reduce_launch(part, dw, 49ll * C, nb, accumulate, s);
 }
 
+// ---- round 5: layer scale folded into the Mlp's second Linear layer (DESIGN.md section 5, round-5 finding 10) -----------------
+namespace {
+// out = x + keep[n] * gamma[c] * (a W2^T + b2)[m, c] with keep in {0, cb}: the GEMM runs on W2' = cb * gamma[c] * W2[c, :] and
+// b2' = cb * gamma[c] * b2[c] with x as its residual addend, and the (few) dropped samples are put right afterwards.
+
+// job row (8 x int64): filter offset (elements, the same in the fp32 parameter arena and in its bf16 shadow), gamma offset, bias
+// offset, folded-bias offset, C (filter rows), K (row length, % 4 == 0), first row of the job in the grid, float bits of cb
+__global__ __launch_bounds__(256) void layerscale_fold_kernel(const float* __restrict__ params, bf16_t* __restrict__ shadow,
+                                                              float* __restrict__ fold_bias, const long long* __restrict__ jobs,
+                                                              int njobs) {
+  const int row = (int)blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && (int)jobs[(j + 1) * 8 + 6] <= row) ++j;
+  const long long* jb = jobs + (long long)j * 8;
+  const int c = row - (int)jb[6], K = (int)jb[5];
+  if (c >= (int)jb[4]) return;
+  const float g = params[jb[1] + c] * __int_as_float((int)jb[7]);
+  const float* w = params + jb[0] + (long long)c * K;
+  bf16_t* o = shadow + jb[0] + (long long)c * K;
+  for (int k = (int)threadIdx.x * 4; k < K; k += 1024) {
+    const f32x4 v = *(const f32x4*)(w + k);
+    u32x2 r;
+    r[0] = pack_bf16x2(g * v[0], g * v[1]);
+    r[1] = pack_bf16x2(g * v[2], g * v[3]);
+    *(u32x2*)(o + k) = r;
+  }
+  if (threadIdx.x == 0) fold_bias[jb[3] + c] = g * params[jb[2] + c];
+}
+
+// For every sample n with keep[n] == 0: dst1[n] = src1 ? src1[n] : 0 (bytes1 per sample) and dst2[n] = 0 (bytes2 per sample).
+// grid (chunks, samples): the workgroups of kept samples leave at once.
+__global__ __launch_bounds__(256) void rows_fix_kernel(const float* __restrict__ keep, unsigned char* __restrict__ dst1,
+                                                       const unsigned char* __restrict__ src1, long long bytes1,
+                                                       unsigned char* __restrict__ dst2, long long bytes2) {
+  const int n = (int)blockIdx.y;
+  if (keep[n] != 0.f) return;
+  const long long stride = (long long)gridDim.x * 256 * 16;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  if (dst1 != nullptr)
+    for (long long o = ((long long)blockIdx.x * 256 + threadIdx.x) * 16; o < bytes1; o += stride)
+      *(u32x4*)(dst1 + n * bytes1 + o) = src1 != nullptr ? *(const u32x4*)(src1 + n * bytes1 + o) : zero;
+  if (dst2 != nullptr)
+    for (long long o = ((long long)blockIdx.x * 256 + threadIdx.x) * 16; o < bytes2; o += stride)
+      *(u32x4*)(dst2 + n * bytes2 + o) = zero;
+}
+
+// partial[n][c] = sum over the rows of sample n of dy[m][c] where keep[n] == 0, else 0 (one workgroup per sample, fixed order)
+__global__ __launch_bounds__(256) void dropped_colsum_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ keep,
+                                                             long long rows_per_image, int C, float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int n = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const int cpr = C >> 3;
+  const bool dropped = keep[n] == 0.f;   // workgroup-uniform
+  for (int cg0 = 0; cg0 < cpr; cg0 += 256) {
+    const int tcols = (cpr - cg0 < 256) ? (cpr - cg0) : 256;
+    const int rlanes = 256 / tcols;
+    const int cgi = tid % tcols, rl = tid / tcols;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    if (dropped && rl < rlanes) {
+      const u32x4* base = (const u32x4*)dy + (long long)n * rows_per_image * cpr + cg0 + cgi;
+      for (long long r = rl; r < rows_per_image; r += rlanes) {
+        const u32x4 v = base[r * cpr];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[2 * e] += bf16_lo(v[e]); s[2 * e + 1] += bf16_hi(v[e]); }
+      }
+    }
+    if (dropped) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
+      __syncthreads();
+    }
+    for (int o = tid; o < tcols * 8; o += 256) {
+      const int cgo = o >> 3, e = o & 7;
+      float t = 0.f;
+      if (dropped)
+        for (int l = 0; l < rlanes; ++l) t += red[(l * tcols + cgo) * 8 + e];
+      partial[(long long)n * C + (cg0 + cgo) * 8 + e] = t;
+    }
+    if (dropped) __syncthreads();
+  }
+}
+
+// One workgroup per output channel c of the folded layer:  S = colsum_all[c] - sum_n dropped[n][c];
+//   dw[c][:] (+)= cb * gamma[c] * G[c][:],  dbias[c] (+)= cb * gamma[c] * S,  dgamma[c] (+)= cb * (<G[c][:], w[c][:]> + bias[c] * S)
+__global__ __launch_bounds__(256) void layerscale_param_grads_kernel(const float* __restrict__ G, const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ colsum_all,
+                                                                     const float* __restrict__ dropped, int n_images, float cb, int C,
+                                                                     int K, float* __restrict__ dw, float* __restrict__ dbias,
+                                                                     float* __restrict__ dgamma, int accumulate) {
+  __shared__ float red[256], red2[256];
+  const int c = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const float gc = gamma[c] * cb;
+  float dot = 0.f, sd = 0.f;
+  const float* g = G + (long long)c * K;
+  const float* wr = w + (long long)c * K;
+  float* o = dw + (long long)c * K;
+  for (int k = tid * 4; k < K; k += 1024) {
+    const f32x4 gv = *(const f32x4*)(g + k), wv = *(const f32x4*)(wr + k);
+    dot += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+    f32x4 r = {gc * gv[0], gc * gv[1], gc * gv[2], gc * gv[3]};
+    if (accumulate) { const f32x4 old = *(const f32x4*)(o + k); r[0] += old[0]; r[1] += old[1]; r[2] += old[2]; r[3] += old[3]; }
+    *(f32x4*)(o + k) = r;
+  }
+  if (dropped != nullptr)
+    for (int n = tid; n < n_images; n += 256) sd += dropped[(long long)n * C + c];
+  red[tid] = dot; red2[tid] = sd;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (tid < h) { red[tid] += red[tid + h]; red2[tid] += red2[tid + h]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float S = colsum_all[c] - red2[0];
+    const float db = gc * S, dg = cb * (red[0] + bias[c] * S);
+    dbias[c] = accumulate ? dbias[c] + db : db;
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  }
+}
+}  // namespace
+
 static unsigned int ls_grid(long long nvec) {
   long long blocks = (nvec + 255) / 256;
   if (blocks > 1024) blocks = 1024;
@@ -612,5 +735,36 @@ int icamd_layerscale_bwd_launch(const bf16_t* dout, const bf16_t* z, const float
   const int rpb = (int)((rows + nblk - 1) / nblk);
   hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dout, z, gamma, keep, dz, part, rows, C, rpb,
                      rows_per_image);
+  return icamd_launch_status();
+}
+
+int icamd_layerscale_fold_launch(const float* params, bf16_t* shadow, float* fold_bias, const long long* jobs, int njobs,
+                                 int total_rows, hipStream_t s) {
+  hipLaunchKernelGGL(layerscale_fold_kernel, dim3((unsigned)total_rows), dim3(256), 0, s, params, shadow, fold_bias, jobs, njobs);
+  return icamd_launch_status();
+}
+
+int icamd_rows_fix_launch(const float* keep, int n_images, void* dst1, const void* src1, long long bytes1, void* dst2,
+                          long long bytes2, hipStream_t s) {
+  const long long big = bytes1 > bytes2 ? bytes1 : bytes2;
+  long long chunks = (big + 65535) / 65536;       // 16 vectors per thread
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(rows_fix_kernel, dim3((unsigned)chunks, (unsigned)n_images), dim3(256), 0, s, keep, (unsigned char*)dst1,
+                     (const unsigned char*)src1, bytes1, (unsigned char*)dst2, bytes2);
+  return icamd_launch_status();
+}
+
+int icamd_dropped_colsum_launch(const bf16_t* dy, const float* keep, int n_images, long long rows_per_image, int C, float* partial,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(dropped_colsum_kernel, dim3((unsigned)n_images), dim3(256), 0, s, dy, keep, rows_per_image, C, partial);
+  return icamd_launch_status();
+}
+
+int icamd_layerscale_param_grads_launch(const float* G, const float* w, const float* bias, const float* gamma,
+                                        const float* colsum_all, const float* dropped, int n_images, float cb, int C, int K,
+                                        float* dw, float* dbias, float* dgamma, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(layerscale_param_grads_kernel, dim3((unsigned)C), dim3(256), 0, s, G, w, bias, gamma, colsum_all, dropped,
+                     n_images, cb, C, K, dw, dbias, dgamma, accumulate);
   return icamd_launch_status();
 }

@@ -100,6 +100,10 @@ _SIGNATURES = {
     "icamd_layerscale_fwd": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_longlong, _P]),
     "icamd_layerscale_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "icamd_layerscale_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_longlong, c_int, _P, c_size_t, _P]),
+    "icamd_layerscale_fold": (c_int, [_P, _P, _P, _P, c_int, c_int, c_longlong, _P]),
+    "icamd_rows_fix": (c_int, [_P, c_int, _P, _P, c_longlong, _P, c_longlong, _P]),
+    "icamd_dropped_colsum": (c_int, [_P, _P, c_int, c_longlong, c_int, _P, _P]),
+    "icamd_layerscale_param_grads": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_float, c_int, c_int, _P, _P, _P, c_int, _P]),
     "icamd_vit_tokens_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "icamd_batch_sum": (c_int, [_P, c_longlong, c_int, c_longlong, _P, c_int, _P]),
     "icamd_strided_rows_copy": (c_int, [_P, c_longlong, _P, c_longlong, c_longlong, c_longlong, _P]),

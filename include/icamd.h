@@ -260,6 +260,33 @@ size_t icamd_layerscale_bwd_workspace_bytes(long long rows, int C);
 int icamd_layerscale_bwd(const void* dout, const void* z, const float* gamma, const float* keep, void* dz, float* dgamma,
                          long long rows, int C, long long rows_per_image, int accumulate, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* Round 5: the layer scale folded into the Mlp's second Linear layer, so that `out = x + drop_path(gamma * fc2(a))`
+ * (ConvNeXt Block.forward of the reference tree's timm model, under model(samples) at /root/reference/engine.py:47) is ONE GEMM with a
+ * residual addend: with keep[n] in {0, cb} (timm's drop_path: cb = 1 / keep_prob; cb = 1 without stochastic depth)
+ *   out[m][c] = x[m][c] + (a W2'^T + b2')[m][c],   W2'[c][:] = cb * gamma[c] * W2[c][:],   b2'[c] = cb * gamma[c] * b2[c]
+ * for every kept sample, and out = x for the dropped ones.
+ * icamd_layerscale_fold: jobs = device array of njobs rows of 8 x int64 {filter offset (elements: the same in the fp32 arena
+ *   `params` and in its bf16 `shadow`), gamma offset, bias offset (both in `params`), folded-bias offset (in fold_bias), C = filter
+ *   rows, K = row length (% 4 == 0), first grid row of the job (rows of all jobs are numbered consecutively, total_rows in all), the
+ *   float bits of cb}: shadow[filter] <- bf16(cb * gamma[c] * params[filter]), fold_bias <- cb * gamma[c] * bias[c].
+ * icamd_rows_fix: for every sample n with keep[n] == 0: dst1[n] <- src1 ? src1[n] : 0 (bytes1 per sample) and dst2[n] <- 0 (bytes2
+ *   per sample; either pair may be NULL; byte counts % 16 == 0).  Forward: out[n] <- x[n] and a[n] <- 0 (so that the dropped
+ *   samples vanish from the weight gradient); backward: the dropped samples' rows of d(fc1 output) <- 0.
+ * icamd_dropped_colsum: partial[n][c] <- sum of the rows of sample n of dy (bf16 [n_images * rows_per_image][C]) where keep[n] == 0,
+ *   zeros for the kept samples.
+ * icamd_layerscale_param_grads: G = dy^T a (fp32 [C][K], the plain weight gradient of the folded layer over ALL rows -- the dropped
+ *   samples' rows of `a` are zero), colsum_all[c] = sum over all rows of dy; S = colsum_all - sum_n dropped[n] (dropped may be NULL):
+ *   dw (+)= cb * gamma[c] * G,  dbias (+)= cb * gamma[c] * S,  dgamma[c] (+)= cb * (<G[c], w[c]> + bias[c] * S[c])   (w, bias: fp32
+ *   parameters of the UNFOLDED layer). */
+int icamd_layerscale_fold(const float* params, void* shadow, float* fold_bias, const long long* jobs, int njobs, int total_rows,
+                          long long total_elements, void* stream);
+int icamd_rows_fix(const float* keep, int n_images, void* dst1, const void* src1, long long bytes1, void* dst2, long long bytes2,
+                   void* stream);
+int icamd_dropped_colsum(const void* dy, const float* keep, int n_images, long long rows_per_image, int C, float* partial,
+                         void* stream);
+int icamd_layerscale_param_grads(const float* G, const float* w, const float* bias, const float* gamma, const float* colsum_all,
+                                 const float* dropped, int n_images, float cb, int C, int K, float* dw, float* dbias,
+                                 float* dgamma, int accumulate, void* stream);
 
 /* ViT token plumbing: tokens[b][0] = cls + pos[0], tokens[b][1+i] = patches[b][i] + pos[1+i] (bf16 out, fp32 parameters);
  * batch_sum: out[j] (+)= sum_b x[b*stride + j] (cls_token / pos_embed gradients); strided row copies; zero fill. */

@@ -32,7 +32,16 @@ def _pair(arch, C, seed=0, drop_path=0.0):
     return ref, net
 
 
-def test_convnext_forward_backward_matches_oracle():
+@pytest.fixture(params=[True, False], ids=["folded_layerscale", "layerscale_kernels"])
+def ls_route(request, monkeypatch):
+    """Both routes of the block tail: the layer scale folded into fc2 (default, ICAMD_FUSED_LAYERSCALE) and the
+    icamd_layerscale_fwd / _bwd kernels of rounds 2-4."""
+    import imageclassification_amd.convnext as cn
+    monkeypatch.setattr(cn, "_FUSED_LS", request.param)
+    return request.param
+
+
+def test_convnext_forward_backward_matches_oracle(ls_route):
     from imageclassification_amd import hip
     C, B, HW = 10, 6, 64
     ref, net = _pair("convnext_test", C, drop_path=0.2)
@@ -75,7 +84,7 @@ def test_convnext_forward_backward_matches_oracle():
     print(f"convnext_test: logits err {err:.2e} (self-noise {noise:.2e}); worst grad err {worst[1]:.2e} at {worst[0]}")
 
 
-def test_hip_convnext_matches_reference_vectors():
+def test_hip_convnext_matches_reference_vectors(ls_route):
     """The HIP ConvNeXt against vectors computed by the REFERENCE's own ConvNeXt class (tests/golden/
     convnext_ref_vectors.npz <- /root/reference/semantic_segmentation/backbone/convnext.py, fp32): stage outputs and every
     parameter gradient of the 4-stage backbone (dims 32/64/96/192, layer scale ~1, non-zero biases), driven through the

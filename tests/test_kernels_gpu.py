@@ -1933,6 +1933,104 @@ def test_dwconv7_lds_tile_form():
 
 
 @pytest.mark.parametrize("use_keep", [False, True])
+def test_folded_layerscale_block_tail(lib, use_keep):
+    """Round 5: the ConvNeXt block tail with the layer scale folded into fc2 (icamd_layerscale_fold + the GEMM's residual addend +
+    icamd_rows_fix; backward: icamd_dropped_colsum + the plain weight gradient + icamd_layerscale_param_grads + the data gradient on
+    the folded filter) against the oracle's three steps fc2 -> layer scale -> drop path (R.layerscale_fwd / _bwd on the fp32
+    Linear layer).  The folded path rounds the filter once (bf16(cb * gamma * W2)) where the three-step path rounds z2: bf16 noise,
+    bound 4e-3 relative; the dropped samples must come out EXACTLY (out = x, zero gradient rows)."""
+    hip = _hip()
+    N, HW, C = 6, 49, 192
+    K, M = 4 * C, N * HW
+    g = torch.Generator().manual_seed(150)
+    a = R.bf16_round(torch.nn.functional.gelu(torch.randn(M, K, generator=g)))
+    x = rnd_bf16(M, C, seed=151)
+    W2 = torch.randn(C, K, generator=g) * K ** -0.5
+    b2 = torch.randn(C, generator=g) * 0.2
+    gamma = 0.3 + torch.rand(C, generator=g)
+    cb = 1.0 / 0.7 if use_keep else 1.0
+    keep = ((torch.rand(N, generator=g) > 0.3).float() * cb) if use_keep else None
+    if use_keep:
+        keep[1], keep[4] = 0.0, cb      # at least one dropped and one kept sample
+    dout = rnd_bf16(M, C, seed=152)
+    # oracle: the three steps in fp32 on the bf16 operands
+    z2 = a @ R.bf16_round(W2).t() + b2
+    ro = R.layerscale_fwd(z2.reshape(N, HW, C), x.reshape(N, HW, C), gamma, keep).reshape(M, C)
+    kk = torch.ones(N) if keep is None else keep
+    dz2 = (dout.reshape(N, HW, C) * kk.reshape(N, 1, 1) * gamma).reshape(M, C)
+    r_dw, r_db = dz2.t() @ a, dz2.sum(0)
+    r_dg = ((dout.reshape(N, HW, C) * kk.reshape(N, 1, 1)).reshape(M, C) * z2).double().sum(0).float()
+    r_da = dz2 @ R.bf16_round(W2)
+    # device: a parameter arena holding W2 | b2 | gamma, its shadow, one fold job
+    arena = torch.cat([W2.flatten(), b2, gamma]).to(DEV)
+    shadow = torch.zeros(arena.numel(), dtype=torch.bfloat16, device=DEV)
+    fold_bias = torch.zeros(C, device=DEV)
+    import struct
+    bits = struct.unpack("<i", struct.pack("<f", cb))[0]
+    jobs = torch.tensor([[0, C * K + C, C * K, 0, C, K, 0, bits]], dtype=torch.int64, device=DEV)
+    s_ = hip.stream_ptr()
+    assert lib.icamd_layerscale_fold(hip.ptr(arena), hip.ptr(shadow), hip.ptr(fold_bias), hip.ptr(jobs), 1, C, C * K, s_) == 0
+    sync()
+    wf = shadow[: C * K].float().cpu().reshape(C, K)
+    assert R.max_bf16_ulp(wf, R.bf16_round(cb * gamma[:, None] * W2)) <= 1.0
+    assert torch.allclose(fold_bias.cpu(), cb * gamma * b2, rtol=1e-6, atol=1e-7)
+    assert torch.all(shadow[C * K:] == 0)
+    ad, xd, dd = to_dev_bf16(a), to_dev_bf16(x), to_dev_bf16(dout)
+    kd = keep.to(DEV) if use_keep else None
+    out = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    d = hip.conv_desc(N, 7, 7, K, C, 1, 1, 1, 0)
+    assert lib.icamd_conv2d_fwd(ctypes.byref(d), hip.ptr(ad), hip.ptr(shadow), hip.ptr(out), hip.ptr(fold_bias), hip.ptr(xd), None,
+                                s_) == 0
+    if use_keep:
+        assert lib.icamd_rows_fix(hip.ptr(kd), N, hip.ptr(out), hip.ptr(xd), HW * C * 2, hip.ptr(ad), HW * K * 2, s_) == 0
+    sync()
+    got = out.float().cpu()
+    assert R.rel_l2(got, ro) <= 4e-3, R.rel_l2(got, ro)
+    if use_keep:
+        dropped = (keep == 0).nonzero().flatten().tolist()
+        assert dropped
+        for n in dropped:
+            assert torch.equal(got[n * HW:(n + 1) * HW], x[n * HW:(n + 1) * HW])
+            assert torch.all(ad[n * HW:(n + 1) * HW] == 0)
+        assert torch.equal(ad.float().cpu()[keep.repeat_interleave(HW) != 0], a[keep.repeat_interleave(HW) != 0])
+    # backward
+    G = torch.empty(C, K, device=DEV)
+    S = torch.empty(C, device=DEV)
+    part = torch.full((N, C), 7.0, device=DEV)
+    wsb = lib.icamd_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = torch.zeros(max(wsb, 256), dtype=torch.uint8, device=DEV)
+    if use_keep:
+        assert lib.icamd_dropped_colsum(hip.ptr(dd), hip.ptr(kd), N, HW, C, hip.ptr(part), s_) == 0
+        sync()
+        rp = dout.reshape(N, HW, C).sum(1) * (keep == 0).float()[:, None]
+        assert torch.allclose(part.cpu(), rp, rtol=1e-5, atol=1e-4)
+    assert lib.icamd_conv2d_wgrad_bias(ctypes.byref(d), hip.ptr(ad), hip.ptr(dd), hip.ptr(G), hip.ptr(S), 0, hip.ptr(ws), wsb, s_) == 0
+    grads = torch.zeros(C * K + 2 * C, device=DEV)
+    for rep, acc in ((1, 0), (2, 1)):
+        assert lib.icamd_layerscale_param_grads(hip.ptr(G), hip.ptr(arena), hip.ptr(arena) + 4 * C * K, hip.ptr(arena) + 4 * (C * K + C),
+                                                hip.ptr(S), hip.ptr(part) if use_keep else None, N, cb, C, K, hip.ptr(grads),
+                                                hip.ptr(grads) + 4 * C * K, hip.ptr(grads) + 4 * (C * K + C), acc, s_) == 0
+        sync()
+        gh = grads.cpu()
+        assert R.rel_l2(gh[: C * K].reshape(C, K), rep * r_dw) <= 2e-3
+        assert R.rel_l2(gh[C * K: C * K + C], rep * r_db) <= 2e-3
+        assert R.rel_l2(gh[C * K + C:], rep * r_dg) <= 2e-3
+    wt = shadow[: C * K].reshape(C, K).t().contiguous()
+    da = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    assert lib.icamd_conv2d_dgrad(ctypes.byref(d), hip.ptr(dd), hip.ptr(wt), hip.ptr(da), None, None, s_) == 0
+    if use_keep:
+        assert lib.icamd_rows_fix(hip.ptr(kd), N, hip.ptr(da), None, HW * K * 2, None, 0, s_) == 0
+    sync()
+    assert R.rel_l2(da.float().cpu(), r_da) <= 6e-3
+    if use_keep:
+        for n in dropped:
+            assert torch.all(da[n * HW:(n + 1) * HW] == 0)
+    # argument checks
+    assert lib.icamd_rows_fix(hip.ptr(kd) if use_keep else hip.ptr(fold_bias), N, None, None, 0, None, 0, s_) != 0
+    assert lib.icamd_rows_fix(hip.ptr(fold_bias), N, hip.ptr(out), None, 24, None, 0, s_) != 0
+
+
+@pytest.mark.parametrize("use_keep", [False, True])
 def test_layerscale_residual_droppath(lib, use_keep):
     hip = _hip()
     N, HW, C = 6, 49, 192
