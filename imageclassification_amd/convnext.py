@@ -583,10 +583,16 @@ class ConvNeXt(PicklableModel):
                 ln_bwd(G[1], b["d"], b["st"], blk["nw"], blk["nb"], G[2], rows, dim)         # G2 = d (dwconv out)
                 bin_ptr, g2, hh, ww_, dd = b["in"].data_ptr(), G[2], h, w, dim
                 dwg = self._gf(blk["dw_w"])
-                lane.launch(lambda st_, bin_ptr=bin_ptr, g2=g2, hh=hh, ww_=ww_, dd=dd, dwg=dwg, nm=blk["name"]: hip.check(
-                    lib.icamd_dwconv7_wgrad(bin_ptr, g2, dwg, acc, dwp, dwb, N, hh, ww_, dd, st_), nm + " dw wgrad"),
-                    reads=(G[2],))
-                hip.check(lib.icamd_colsum_rows(G[2], rows, dim, dim, self._gf(blk["dw_b"]), acc, csp, csb, s), "dw bias grad")
+                if lib.icamd_dwconv7_wgrad_bias_supported(N, hh, ww_, dd):   # filter and bias gradient out of one pass over dy
+                    dbg = self._gf(blk["dw_b"])
+                    lane.launch(lambda st_, bin_ptr=bin_ptr, g2=g2, hh=hh, ww_=ww_, dd=dd, dwg=dwg, dbg=dbg, nm=blk["name"]: hip.check(
+                        lib.icamd_dwconv7_wgrad_bias(bin_ptr, g2, dwg, dbg, acc, dwp, dwb, N, hh, ww_, dd, st_), nm + " dw wgrad+bias"),
+                        reads=(G[2],))
+                else:
+                    lane.launch(lambda st_, bin_ptr=bin_ptr, g2=g2, hh=hh, ww_=ww_, dd=dd, dwg=dwg, nm=blk["name"]: hip.check(
+                        lib.icamd_dwconv7_wgrad(bin_ptr, g2, dwg, acc, dwp, dwb, N, hh, ww_, dd, st_), nm + " dw wgrad"),
+                        reads=(G[2],))
+                    hip.check(lib.icamd_colsum_rows(G[2], rows, dim, dim, self._gf(blk["dw_b"]), acc, csp, csb, s), "dw bias grad")
                 hip.check(lib.icamd_dwconv7_dgrad(G[2], self.shadow.data_ptr() + 2 * blk["dw_w"].offset, dout, W(other), N, h, w,
                                                   dim, s), blk["name"] + " dw dgrad")        # + residual gradient
                 dout, other = other, dout

@@ -89,8 +89,9 @@ int icamd_attention_bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_
 int icamd_dwconv7_launch(const bf16_t* x, const bf16_t* w, const float* bias, const bf16_t* addend, bf16_t* y, int N, int H,
                          int W, int C, int flip, hipStream_t s);
 int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C);
-int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, int N, int H, int W, int C,
+int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, float* dbias, int N, int H, int W, int C,
                                int accumulate, hipStream_t s);
+bool icamd_dwconv7_wgrad_bias_supported_cxx(int N, int H, int W, int C);
 int icamd_layerscale_fwd_launch(const bf16_t* z, const bf16_t* inp, const float* gamma, const float* keep, bf16_t* out,
                                 long long rows, int C, long long rows_per_image, hipStream_t s);
 int icamd_layerscale_bwd_blocks(long long rows);
@@ -936,7 +937,7 @@ int icamd_dwconv7_dgrad(const void* dy, const void* w, const void* addend, void*
 
 size_t icamd_dwconv7_wgrad_workspace_bytes(int N, int H, int W, int C) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0) return 0;
-  return (size_t)icamd_dwconv7_wgrad_blocks(N, H, W, C) * 49 * C * sizeof(float);
+  return (size_t)icamd_dwconv7_wgrad_blocks(N, H, W, C) * 50 * C * sizeof(float);   // [blocks][49][C] + the bias rows [blocks][C]
 }
 
 int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
@@ -946,7 +947,22 @@ int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate
   if (x == nullptr || dy == nullptr || dw == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
   const size_t need = icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C);
   if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
-  return icamd_dwconv7_wgrad_launch((const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, dw, N, H, W, C, accumulate,
+  return icamd_dwconv7_wgrad_launch((const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, dw, nullptr, N, H, W, C, accumulate,
+                                    (hipStream_t)stream);
+}
+
+int icamd_dwconv7_wgrad_bias_supported(int N, int H, int W, int C) {
+  return (N > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && ::icamd_dwconv7_wgrad_bias_supported_cxx(N, H, W, C)) ? 1 : 0;
+}
+
+int icamd_dwconv7_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, int accumulate, void* workspace,
+                             size_t workspace_bytes, int N, int H, int W, int C, void* stream) {
+  ProfScope _prof(PC_DWCONV, stream);
+  _prof.work(4.0 * N * H * W * C, 100.0 * N * H * W * C);
+  if (x == nullptr || dy == nullptr || dw == nullptr || dbias == nullptr || workspace == nullptr) return ICAMD_ERR_BAD_ARG;
+  const size_t need = icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C);
+  if (need == 0 || workspace_bytes < need) return ICAMD_ERR_WORKSPACE;
+  return icamd_dwconv7_wgrad_launch((const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, dw, dbias, N, H, W, C, accumulate,
                                     (hipStream_t)stream);
 }
 

@@ -320,11 +320,14 @@ template <int R0, int NR>
 __device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ xB, const unsigned char* __restrict__ dB,
                                               float* __restrict__ part, float* red, bool active, unsigned int xo, unsigned int dyo,
                                               unsigned int cb, unsigned int rowb, unsigned int colmask, int w0, int H, int W, int C,
-                                              int cpr_wg, int groups, int cslice, long long ib) {
+                                              int cpr_wg, int groups, int cslice, long long ib, float* __restrict__ part_b) {
   const int tid = threadIdx.x;
   f32x2 acc[NR * 7];
 #pragma unroll
   for (int k = 0; k < NR * 7; ++k) acc[k] = f32x2{0.f, 0.f};
+  // round 5: the first pass loads every dy row of the strip exactly once (rows 0..2 ahead of the walk, row h + 3 at x row h), so
+  // the bias gradient sum(dy) falls out of it for seven packed adds per row (it was a separate pass over dy: icamd_colsum_rows)
+  f32x2 bacc = f32x2{0.f, 0.f};
   if (active) {
     f32x2 dr[NR][7];                                         // ring: dy row hd lives in slot hd mod NR
     auto load_dy = [&](auto slotc, int hd) {
@@ -334,6 +337,7 @@ __device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ 
       for (int o = 0; o < 7; ++o) {
         const unsigned int v = (hd >= 0 && hd < H && w0 + o < W) ? ld_stream((const unsigned int*)(dB + (ro + (unsigned)o * cb))) : 0u;
         dr[S][o] = f32x2{bf16_lo(v), bf16_hi(v)};
+        if constexpr (R0 == 0) bacc = bacc + dr[S][o];
       }
     };
     // what x row 0 needs besides the row it loads itself: dy rows 4 - R0 - NR .. 2 - R0 (zeros where outside the image)
@@ -384,11 +388,25 @@ __device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ 
       part[((long long)ib * 49 + (R0 + RR) * 7 + (k2 >> 1)) * C + (cslice * cpr_wg + l) * 2 + (k2 & 1)] = sum;
     }
   });
+  if constexpr (R0 == 0) {
+    if (part_b != nullptr) {      // the bias partial row of this workgroup, same fixed-order sum over the groups
+      __syncthreads();
+      red[tid] = bacc[0];
+      red[256 + tid] = bacc[1];
+      __syncthreads();
+      for (int idx = tid; idx < 2 * cpr_wg; idx += 256) {
+        const int k2 = idx / cpr_wg, l = idx - k2 * cpr_wg;
+        float sum = 0.f;
+        for (int g = 0; g < groups; ++g) sum += red[k2 * 256 + g * cpr_wg + l];
+        part_b[(long long)ib * C + (cslice * cpr_wg + l) * 2 + k2] = sum;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void dwconv7_wgrad_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                    float* __restrict__ part, int N, int H, int W, int C,
-                                                                    int nstrips, int groups) {
+                                                                    float* __restrict__ part, float* __restrict__ part_b, int N,
+                                                                    int H, int W, int C, int nstrips, int groups) {
   // workgroup = `groups` (n, strip) items x cpr_wg channel pairs, cpr_wg * groups == 256; blockIdx.x = cslice + nslices * item_block
   __shared__ float red[7 * 2 * 256];   // one kernel row of taps at a time (14 KB)
   const int cpr = C >> 1;
@@ -411,9 +429,9 @@ __global__ __launch_bounds__(256, 2) void dwconv7_wgrad_rows_kernel(const bf16_t
   const unsigned int xo = img + (unsigned)(w0 - 3) * cb + (unsigned)c * 2u;
   const unsigned int dyo = img + (unsigned)w0 * cb + (unsigned)c * 2u;
   dw_wgrad_pass<0, 4>((const unsigned char*)x, (const unsigned char*)dy, part, red, active, xo, dyo, cb, rowb, colmask, w0, H, W, C,
-                      cpr_wg, groups, cslice, ib);
+                      cpr_wg, groups, cslice, ib, part_b);
   dw_wgrad_pass<4, 3>((const unsigned char*)x, (const unsigned char*)dy, part, red, active, xo, dyo, cb, rowb, colmask, w0, H, W, C,
-                      cpr_wg, groups, cslice, ib);
+                      cpr_wg, groups, cslice, ib, nullptr);
 }
 
 // out = inp + keep[b] * gamma[c] * z      (rows_per_image rows of C channels per sample; keep may be NULL)
@@ -565,19 +583,27 @@ int icamd_dwconv7_wgrad_blocks(int N, int H, int W, int C) {
   return (int)nb;
 }
 
-int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, int N, int H, int W, int C,
+// dbias != NULL (round 5): sum(dy) per channel out of the same pass (rows kernel only: icamd_dwconv7_wgrad_bias_supported_cxx);
+// its partial rows [ib][C] follow the [ib][49][C] filter partials in the workspace
+bool icamd_dwconv7_wgrad_bias_supported_cxx(int N, int H, int W, int C) { return C % CG == 0 && dw_rows_usable(N, H, W, C); }
+
+int icamd_dwconv7_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* part, float* dw, float* dbias, int N, int H, int W, int C,
                                int accumulate, hipStream_t s) {
   if (C % CG != 0) return ICAMD_ERR_UNSUPPORTED;
   if (dw_rows_usable(N, H, W, C)) {
     int nstrips, groups, nslices; long long ib;
     dw_wgrad_rows_geometry(N, W, C, &nstrips, &groups, &nslices, &ib);
     if (ib * nslices >= (1ll << 31)) return ICAMD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(dwconv7_wgrad_rows_kernel, dim3((unsigned)(ib * nslices)), dim3(256), 0, s, x, dy, part, N, H, W, C,
+    float* part_b = dbias != nullptr ? part + ib * 49 * C : nullptr;
+    hipLaunchKernelGGL(dwconv7_wgrad_rows_kernel, dim3((unsigned)(ib * nslices)), dim3(256), 0, s, x, dy, part, part_b, N, H, W, C,
                        nstrips, groups);
     int rc = icamd_launch_status();
     if (rc) return rc;
-    return icamd_slab_reduce_launch(part, dw, 49ll * C, (int)ib, accumulate, s);
+    rc = icamd_slab_reduce_launch(part, dw, 49ll * C, (int)ib, accumulate, s);
+    if (rc || dbias == nullptr) return rc;
+    return icamd_slab_reduce_launch(part_b, dbias, (long long)C, (int)ib, accumulate, s);
   }
+  if (dbias != nullptr) return ICAMD_ERR_UNSUPPORTED;
   const int nb = icamd_dwconv7_wgrad_blocks(N, H, W, C);
   hipLaunchKernelGGL(dwconv7_wgrad_kernel, dim3((unsigned)(nb * (C / CG))), dim3(256), 0, s, x, dy, part, N, H, W, C, nb);
   // fold the nb partial rows with the slab reducer (many workgroups, fixed order) -- 49*C is a multiple of 4

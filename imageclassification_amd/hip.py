@@ -97,6 +97,8 @@ _SIGNATURES = {
     "icamd_dwconv7_dgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "icamd_dwconv7_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "icamd_dwconv7_wgrad": (c_int, [_P, _P, _P, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
+    "icamd_dwconv7_wgrad_bias_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "icamd_dwconv7_wgrad_bias": (c_int, [_P, _P, _P, _P, c_int, _P, c_size_t, c_int, c_int, c_int, c_int, _P]),
     "icamd_layerscale_fwd": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_longlong, _P]),
     "icamd_layerscale_bwd_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "icamd_layerscale_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_longlong, c_int, c_longlong, c_int, _P, c_size_t, _P]),

@@ -252,6 +252,12 @@ size_t icamd_dwconv7_wgrad_workspace_bytes(int N, int H, int W, int C);
 /* dw fp32 [7][7][C] (+)= sum over pixels dy * shifted x */
 int icamd_dwconv7_wgrad(const void* x, const void* dy, float* dw, int accumulate, void* workspace, size_t workspace_bytes,
                         int N, int H, int W, int C, void* stream);
+/* Round 5: the same pass also leaves the bias gradient dbias fp32 [C] (+)= sum over pixels dy (every dy row passes through the
+ * kernel's registers once): replaces a separate icamd_colsum_rows pass over dy.  _supported: 1 where the register-sliding-window
+ * kernel runs (the shapes of ConvNeXt-T at any batch); elsewhere the call returns ICAMD_ERR_UNSUPPORTED and the two calls remain. */
+int icamd_dwconv7_wgrad_bias_supported(int N, int H, int W, int C);
+int icamd_dwconv7_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, int accumulate, void* workspace,
+                             size_t workspace_bytes, int N, int H, int W, int C, void* stream);
 /* out = inp + keep[sample] * gamma[c] * z  (layer scale + stochastic depth + residual; keep NULL = 1; rows_per_image
  * rows of C channels per sample).  bwd: dz = dout*keep*gamma, dgamma (+)= sum dout*z*keep (workspace zero-filled once). */
 int icamd_layerscale_fwd(const void* z, const void* inp, const float* gamma, const float* keep, void* out, long long rows, int C,

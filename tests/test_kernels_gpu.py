@@ -1857,13 +1857,14 @@ def test_partial_sum_kernels_bits_do_not_depend_on_a_second_stream(lib, which):
         dy = (torch.randn(N, H, W, C, device=DEV, generator=g) * 1e-3).bfloat16()
         wsb = lib.icamd_dwconv7_wgrad_workspace_bytes(N, H, W, C)
         ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
-        outs = [torch.empty(C, 7, 7, device=DEV)]
+        outs = [torch.empty(C, 7, 7, device=DEV), torch.empty(C, device=DEV)]
 
-        def run():
-            assert lib.icamd_dwconv7_wgrad(hip.ptr(x), hip.ptr(dy), hip.ptr(outs[0]), 0, hip.ptr(ws), wsb, N, H, W, C,
-                                           main.cuda_stream) == 0
+        def run():   # (round 5: the bias gradient rides in the same pass -- one more per-thread packed sum)
+            assert lib.icamd_dwconv7_wgrad_bias(hip.ptr(x), hip.ptr(dy), hip.ptr(outs[0]), hip.ptr(outs[1]), 0, hip.ptr(ws), wsb,
+                                                N, H, W, C, main.cuda_stream) == 0
         _, rdw = R.dwconv7_bwd(x.float().cpu(), torch.zeros(C, 7, 7), dy.float().cpu())
-        oracle = {0: (rdw.permute(1, 2, 0).contiguous(), 1e-4)}    # the kernel's layout is [7][7][C]
+        oracle = {0: (rdw.permute(1, 2, 0).contiguous(), 1e-4),    # the kernel's layout is [7][7][C]
+                  1: (dy.float().cpu().reshape(-1, C).double().sum(0).float(), 1e-4)}
 
     run()
     sync()
@@ -1918,6 +1919,22 @@ def test_dwconv7_fwd_dgrad_wgrad(lib, shape):
     sync()
     assert R.rel_l2(dx.float().cpu(), rdx) <= 1e-3 and R.bf16_close(dx.float().cpu(), rdx)
     assert R.rel_l2(dw.cpu(), 1.0 + rdw.permute(1, 2, 0)) <= 1e-4
+    # round 5: filter and bias gradient out of one pass (the register sliding-window kernel); refused elsewhere
+    dw2 = torch.full((7, 7, C), float("nan"), device=DEV)
+    db2 = torch.full((C,), 2.0, device=DEV)
+    rdb = dy.reshape(-1, C).double().sum(0).float()
+    if lib.icamd_dwconv7_wgrad_bias_supported(N, H, W, C):
+        for acc, base in ((0, 0.0), (1, 1.0)):
+            if acc:
+                dw2.fill_(1.0); db2.fill_(1.0)
+            assert lib.icamd_dwconv7_wgrad_bias(hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw2), hip.ptr(db2), acc, hip.ptr(ws), wsb, N, H, W, C,
+                                                hip.stream_ptr()) == 0
+            sync()
+            assert R.rel_l2(dw2.cpu(), base + rdw.permute(1, 2, 0)) <= 1e-4
+            assert torch.allclose(db2.cpu(), base + rdb, rtol=1e-5, atol=1e-4 * max(1.0, float(rdb.abs().max())))
+    else:
+        assert lib.icamd_dwconv7_wgrad_bias(hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw2), hip.ptr(db2), 0, hip.ptr(ws), wsb, N, H, W, C,
+                                            hip.stream_ptr()) != 0
 
 
 def test_dwconv7_lds_tile_form():
