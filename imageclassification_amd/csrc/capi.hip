@@ -209,17 +209,22 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     h.N = d->N; h.H = d->IH; h.W = d->IW; h.C = d->Cin; h.Cout = d->Cout;
     return icamd_halo3x3_launch(h, (hipStream_t)stream);
   }
-  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && bias == nullptr && addend == nullptr && !relu &&
+  // round 5: a 1x1 / stride-2 convolution (ResNet's projection shortcuts) is the same pointwise problem on the rows (n, 2 oh, 2 ow):
+  // the register-resident kernel gathers them in its LDS-DMA staging (ICAMD_PW_S2=0: back on conv_igemm)
+  static const bool pw_s2 = [] { const char* e = getenv("ICAMD_PW_S2"); return !(e && atoi(e) == 0); }();
+  const bool pw_gather = d->KH == 1 && d->KW == 1 && d->stride == 2 && d->pad == 0 && pw_s2 && addend == nullptr;
+  if (d->KH == 1 && d->KW == 1 && (d->stride == 1 || pw_gather) && d->pad == 0 && bias == nullptr && addend == nullptr && !relu &&
       gelu_out == nullptr && !gelu_inplace && icamd_pw_resident_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin)) {
     PwResidentParams g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.stats = stats;
     g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
+    if (pw_gather) { g.gat_oh = d->OH; g.gat_ow = d->OW; g.gat_ih = d->IH; g.gat_iw = d->IW; }
     return icamd_pw_resident_launch(g, (hipStream_t)stream);
   }
   // evaluate()'s BatchNorm-folded forward (bias = the folded shift, optional residual addend, ReLU): the same register-resident
   // kernel with the inference epilogue (round 4; these launches ran on conv_igemm's single-stage tiles before)
-  if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (bias != nullptr || relu) && stats == nullptr &&
+  if (d->KH == 1 && d->KW == 1 && (d->stride == 1 || pw_gather) && d->pad == 0 && (bias != nullptr || relu) && stats == nullptr &&
       gelu_out == nullptr && !gelu_inplace && icamd_pw_resident_epi_wanted() &&
       icamd_pw_resident_wanted((long long)d->N * d->OH * d->OW, d->Cout, d->Cin, addend != nullptr)) {
     PwResidentParams g;
@@ -227,6 +232,7 @@ static int conv_fwd_impl(const icamd_conv_desc* d, const void* x, const void* w,
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)w; g.out = (bf16_t*)y; g.bias = bias; g.relu = relu;
     g.addend = (const bf16_t*)addend;
     g.M = d->N * d->OH * d->OW; g.N = d->Cout; g.K = d->Cin;
+    if (pw_gather) { g.gat_oh = d->OH; g.gat_ow = d->OW; g.gat_ih = d->IH; g.gat_iw = d->IW; }
     return icamd_pw_resident_launch(g, (hipStream_t)stream);
   }
   if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && addend == nullptr && !relu && stats == nullptr &&

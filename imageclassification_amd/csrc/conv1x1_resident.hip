@@ -117,7 +117,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_resident_kernel(const PwReside
       const int pos = (byte % ROWB) >> 4;
       const int chunk = pos ^ sw(row);
       const int m = m0 + row;
-      const bf16_t* src = m < m_end ? p.A + ((long long)m * p.K + chunk * 8) : zero;
+      long long srow = m;
+      if constexpr (!EXT && !ADD && !BNR) {
+        if (p.gat_ow > 0) {     // stride-2 gather: the source row of output pixel (n, oh, ow) is input pixel (n, 2 oh, 2 ow)
+          const unsigned int n = fdiv((unsigned)m, p.gdivHW);
+          const unsigned int rem = (unsigned)m - n * (unsigned)(p.gat_oh * p.gat_ow);
+          const unsigned int oh = fdiv(rem, p.gdivW);
+          const unsigned int ow = rem - oh * (unsigned)p.gat_ow;
+          srow = ((long long)n * p.gat_ih + 2 * oh) * p.gat_iw + 2 * ow;
+        }
+      }
+      const bf16_t* src = m < m_end ? p.A + (srow * p.K + chunk * 8) : zero;
       if constexpr (EXT) {
         // columns >= Ktrue of a staged row come from the zero page (round 5, ADVICE r4: read as the first columns of the NEXT row
         // and multiplied by the zero filter columns, one Inf / NaN in row m + 1 -- possibly the next image -- poisoned every output
@@ -598,6 +608,11 @@ int icamd_pw_resident_launch(PwResidentParams& p, hipStream_t stream) {
   if (p.sub2_h > 0) {
     p.divHW = make_fastdiv((unsigned)(p.sub2_h * p.sub2_w));
     p.divW = make_fastdiv((unsigned)p.sub2_w);
+  }
+  if (p.gat_ow > 0) {
+    if (p.addend != nullptr) return ICAMD_ERR_UNSUPPORTED;
+    p.gdivHW = make_fastdiv((unsigned)(p.gat_oh * p.gat_ow));
+    p.gdivW = make_fastdiv((unsigned)p.gat_ow);
   }
   const int grid = S * p.ntiles_n;
   p.xcd_groups = xcd_order();

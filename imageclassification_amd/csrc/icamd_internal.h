@@ -109,6 +109,10 @@ struct PwResidentParams {
   bf16_t* gelu_out;               // optional second output: gelu(rounded out)
   int gelu_inplace;               // out itself receives gelu(rounded result)
   const bf16_t* gelu_z;           // optional [M][N]: out = rounded result * gelu'(gelu_z)
+  // round 5, stride-2 pointwise forward (ResNet's projection shortcuts): output row m = (n, oh, ow) of [.][gat_oh][gat_ow] reads
+  // input row (n, 2 oh, 2 ow) of [.][gat_ih][gat_iw]; 0: rows are read in order
+  int gat_oh, gat_ow, gat_ih, gat_iw;
+  FastDiv gdivHW, gdivW;          // filled by the launcher when gat_ow > 0
 };
 bool icamd_pw_resident_wanted(long long M, int N, int K, bool with_addend = false);
 bool icamd_pw_resident_epi_wanted();   // ICAMD_PW_RESIDENT_EPI=0: evaluate()'s pointwise layers stay on conv_igemm (A/B, tests)

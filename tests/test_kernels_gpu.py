@@ -286,6 +286,12 @@ def test_pointwise_register_resident_filter_every_shape():
         "             (2, 8, 8, 256, 1024, 1, 1, 0), (1, 13, 11, 256, 128, 1, 1, 0), (2, 9, 7, 256, 64, 1, 1, 0),\n"
         "             (2, 6, 6, 512, 2048, 1, 1, 0), (1, 8, 8, 512, 128, 1, 1, 0)]:\n"
         "    T.test_conv_fwd_act_and_bn_fold(lib, case)\n"
+        "# round 5: 1x1 / stride 2 (projection shortcuts) as a row gather in the same kernel: statistics form and inference form,\n"
+        "# even and odd input sizes, a batch large enough for several tiles per workgroup\n"
+        "for case in [(2, 14, 14, 256, 512, 1, 2, 0), (3, 13, 11, 128, 256, 1, 2, 0), (2, 12, 12, 512, 1024, 1, 2, 0),\n"
+        "             (40, 56, 56, 256, 512, 1, 2, 0)]:\n"
+        "    T.test_conv_fwd_with_stats_bias_addend(lib, case)\n"
+        "    T.test_conv_fwd_act_and_bn_fold(lib, case)\n"
         "print('forced-ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, ICAMD_PW_RESIDENT="2")
