@@ -70,6 +70,7 @@ else
   # round 5: the fused conv3 + bn3 backward against the three launches it replaces; the Linear-layer weight gradients (8-phase vs ring)
   python3 tools/fused_bwd_probe.py 20 2>&1 | grep -v amdgpu.ids > $O/fused_bwd.txt
   python3 tools/fused_fwd_probe.py 20 2>&1 | grep -v amdgpu.ids > $O/fused_fwd.txt
+  python3 tools/ls_fuse_probe.py 20 2>&1 | grep -v amdgpu.ids > $O/ls_fuse.txt
   for e in 1 0; do for s in "50432 768 3072" "50432 3072 768" "50432 768 2304" "50432 768 768" "12544 768 3072" "50176 1024 512"; do
     echo -n "ICAMD_WGRAD_8PHASE=$e "; ICAMD_WGRAD_8PHASE=$e python3 tools/wgrad_probe.py $s 2>&1 | grep TFLOP; done; done > $O/wgrad_shapes.txt
   # 10 steps per PMC run: 1 warm-up + 3 timed + the 3-step host-enqueue burst + 3 in the per-class timing pass

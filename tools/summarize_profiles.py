@@ -46,7 +46,7 @@ def copy(src, dst):
 for src, dst in [("bench_r50.json", "bench_n1.json"), ("bench_vit.json", "bench_vit.json"), ("bench_cnx.json", "bench_convnext.json"),
                  ("bench_eval.json", "bench_eval.json"), ("pmc_traffic_eval.json", "pmc_traffic_eval.json"),
                  ("layers.txt", "per_layer_table.txt"), ("gemm_shapes.txt", "gemm_shapes.txt"), ("dwconv.txt", "dwconv.txt"), ("cnx_layers.txt", "convnext_linear_layers.txt"), ("attention.txt", "attention.txt"),
-                 ("fused_bwd.txt", "fused_conv_bn_bwd.txt"), ("fused_fwd.txt", "fused_bn_apply_conv.txt"), ("wgrad_shapes.txt", "wgrad_shapes.txt"),
+                 ("fused_bwd.txt", "fused_conv_bn_bwd.txt"), ("fused_fwd.txt", "fused_bn_apply_conv.txt"), ("ls_fuse.txt", "convnext_layerscale_fold.txt"), ("wgrad_shapes.txt", "wgrad_shapes.txt"),
                  ("pmc_traffic_r50.json", "pmc_traffic.json"), ("pmc_traffic_vit.json", "pmc_traffic_vit.json"),
                  ("pmc_traffic_cnx.json", "pmc_traffic_convnext.json")]:
     copy(src, dst)
