@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int nvec = C >> 3;
-  const bool has[2] = {sub < nvec, NV > 1 && sub + LPR < nvec};
+  bool has[NV];
+#pragma unroll
+  for (int it = 0; it < NV; ++it) has[it] = sub + it * LPR < nvec;
   float g[NV][8], bt[NV][8];
 #pragma unroll
   for (int it = 0; it < NV; ++it) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
 // dx = rstd * (dy*gamma - mean_C(dy*gamma) - xhat * mean_C(dy*gamma*xhat)) (+ addend); per-workgroup partial column
 // sums of dy (-> dbeta) and dy*xhat (-> dgamma) in part[blk][2][C].  Each wave walks `rows_per_wave` rows, 64/LPR at a time.
 template <int LPR, int NV>
-__global__ __launch_bounds__(256, NV == 1 ? 4 : 3) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(256, NV == 1 ? 4 : (NV == 2 ? 3 : 2)) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const bf16_t* __restrict__ addend,
                                                             bf16_t* __restrict__ dx, float* __restrict__ part, long long rows,
@@ -114,7 +116,9 @@ __global__ __launch_bounds__(256, NV == 1 ? 4 : 3) void layernorm_bwd_kernel(con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int nvec = C >> 3;
-  const bool has[2] = {sub < nvec, NV > 1 && sub + LPR < nvec};
+  bool has[NV];
+#pragma unroll
+  for (int it = 0; it < NV; ++it) has[it] = sub + it * LPR < nvec;
   // Column sums (d beta, d gamma) and gamma as PACKED pairs in the order the 16 B vectors hold them (element 2e in .x, 2e + 1
   // in .y): every pair the packed-fp32 instructions see is then a natural VGPR pair and no op_sel swizzle is needed.  That is
   // a correctness matter on this part, not a style one -- see the note at the accumulation below.
@@ -347,6 +351,20 @@ inline unsigned int ew_grid(long long nvec) {
 }  // namespace
 
 static inline int ln_lanes_per_row(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
+// round 5: rows of 3 * 2^k vectors (every ConvNeXt width and ViT-B's 768: 12 / 24 / 48 / 96 vectors) as THREE vectors per lane on
+// 4 / 8 / 16 / 32 lanes -- no idle lanes (the one- and two-vector forms leave a quarter of them idle on these widths; the two-vector
+// backward also spilled 3-4 registers at its three workgroups per CU).  Measured, two A/B pairs on one box: ViT-B/16 (C = 768)
+// 35.93 / 36.02 -> 35.60 / 35.62 ms with both directions on the three-vector form, forward alone -0.1, backward alone -0.15;
+// ConvNeXt-T (C = 96 ... 384, one vector per lane today) 26.8-27.0 either way -- so only the 768-wide rows take it by default.
+// ICAMD_LN_NV3: bit 0 forward, bit 1 backward (default 3), bit 2 every eligible width.
+static inline int ln_nv3_lanes(int C, int mode_bit) {
+  static const int mode = [] { const char* e = getenv("ICAMD_LN_NV3"); return e ? atoi(e) : 3; }();
+  const int nvec = C >> 3;
+  if (!(mode & mode_bit) || nvec % 3 != 0) return 0;
+  const int l = nvec / 3;
+  if (l == 32) return l;
+  return ((mode & 4) && (l == 4 || l == 8 || l == 16)) ? l : 0;
+}
 
 int icamd_layernorm_fwd_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                                long long rows, int C, float eps, hipStream_t s) {
@@ -358,6 +376,13 @@ int icamd_layernorm_fwd_launch(const bf16_t* x, const float* gamma, const float*
   const dim3 grid((unsigned)blocks), block(256);
   const bool one = C <= 8 * lpr;   // one 16 B vector per lane
 #define ICAMD_LN_FWD(L, V) hipLaunchKernelGGL((layernorm_fwd_kernel<L, V>), grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps)
+  if (const int l3 = ln_nv3_lanes(C, 1)) {
+    long long b3 = (rows + 4 * (64 / l3) - 1) / (4 * (64 / l3));
+    if (b3 > 2048) b3 = 2048;
+    const dim3 grid((unsigned)(b3 < 1 ? 1 : b3));
+    if (l3 == 4) ICAMD_LN_FWD(4, 3); else if (l3 == 8) ICAMD_LN_FWD(8, 3); else if (l3 == 16) ICAMD_LN_FWD(16, 3); else ICAMD_LN_FWD(32, 3);
+    return icamd_launch_status();
+  }
   if (lpr == 16) { if (one) ICAMD_LN_FWD(16, 1); else ICAMD_LN_FWD(16, 2); }
   else if (lpr == 32) { if (one) ICAMD_LN_FWD(32, 1); else ICAMD_LN_FWD(32, 2); }
   else { if (one) ICAMD_LN_FWD(64, 1); else ICAMD_LN_FWD(64, 2); }
@@ -381,6 +406,10 @@ int icamd_layernorm_bwd_launch(const bf16_t* dy, const bf16_t* x, const float* m
   const bool one = C <= 8 * lpr;
 #define ICAMD_LN_BWD(L, V) \
   hipLaunchKernelGGL((layernorm_bwd_kernel<L, V>), grid, block, 0, s, dy, x, mean, rstd, gamma, addend, dx, part, rows, C, rpw)
+  if (const int l3 = ln_nv3_lanes(C, 2)) {
+    if (l3 == 4) ICAMD_LN_BWD(4, 3); else if (l3 == 8) ICAMD_LN_BWD(8, 3); else if (l3 == 16) ICAMD_LN_BWD(16, 3); else ICAMD_LN_BWD(32, 3);
+    return icamd_launch_status();
+  }
   if (lpr == 16) { if (one) ICAMD_LN_BWD(16, 1); else ICAMD_LN_BWD(16, 2); }
   else if (lpr == 32) { if (one) ICAMD_LN_BWD(32, 1); else ICAMD_LN_BWD(32, 2); }
   else { if (one) ICAMD_LN_BWD(64, 1); else ICAMD_LN_BWD(64, 2); }

@@ -1690,6 +1690,27 @@ def test_attention_fwd_bwd(lib, B, T, H):
         assert R.rel_l2(gd[:, sl], rd[:, sl]) <= 6e-3, name      # P, dS pass through bf16 MFMA operands
 
 
+@pytest.mark.parametrize("mode", ["7", "0"])
+def test_layernorm_every_lane_layout(mode):
+    """Round 5: rows of 3 * 2^k vectors run as three vectors per lane on 4 / 8 / 16 / 32 lanes (default for the 768-wide rows only);
+    ICAMD_LN_NV3=7 routes every eligible width there, 0 none (the one- / two-vector forms of round 4).  Child process: the switch is
+    read once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_kernels_gpu as T\n"
+        "from imageclassification_amd import hip\n"
+        "lib = hip.load()\n"
+        "for rows, C in [(64, 96), (37, 192), (33, 384), (50, 768), (197 * 3, 768), (5, 1024)]:\n"
+        "    T.test_layernorm_fwd_bwd(lib, rows, C)\n"
+        "print('forced-ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, ICAMD_LN_NV3=mode)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "forced-ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_layernorm_bwd_bits_do_not_depend_on_a_second_stream(lib):
     """The per-workgroup column sums of layernorm_bwd_kernel (d gamma, d beta) must not depend on what else runs on the GPU.
     Round 3: with a ring weight gradient on a second stream (what the model's backward does) ~3 % of the partial rows of the
