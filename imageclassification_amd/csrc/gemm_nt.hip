@@ -349,6 +349,15 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
 //     every part paid 40-60 us for writing back its XCD's L2): 252.6 -> 246.9 / 254.8 / 254.7 us at K = 3072, 204 -> 192-203
 //     at K = 2304, 73 -> 87 at K = 768 -- inside the run-to-run spread, because the 79 tiles of a partial round run faster
 //     than the tiles of a full one (the shared L2 -> LDS delivery is the bound, not the count of busy CUs).
+//     Round 5, the same split once more with the parts of a tile placed on ONE XCD (workgroups 8 apart; HW_REG_XCC_ID confirmed
+//     workgroup b on XCD b mod 8 in every launch) so that the partial tiles meet in that XCD's L2 -- plain stores, vmcnt(0), a
+//     relaxed device-scope ticket, the last arriver sums the parts in part order: correct, bit-stable, and slower again: K = 3072
+//     251-258 -> 260-266 us, K = 2304 174-189 -> 197-213, K = 768 75 -> 92-100.  The 237 parts write 60 MB of partial tiles at the
+//     same moment, 7.7 MB per XCD into a 4 MB L2, and read them back: ~35 us at the very end of the kernel with nothing left to
+//     overlap it, against the 25-30 us the shorter tail saves.  The vendor GEMM on these shapes (rocprofv3: Custom_Cijk_..._SK3_...
+//     MT256x256x64, 922-1060 TFLOP/s) is a Stream-K kernel: every CU walks an equal, contiguous share of ALL K iterations, so the
+//     same volume of partial tiles is exchanged all along the run, under other CUs' MFMAs -- a persistent form of this kernel,
+//     which round 3 measured 5 % slower than one workgroup per tile, would have to come first.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int PIECE = 16384, KTILE = 65536;   // bytes: one piece, one K tile (pieces in stream order A_mh0, B_nh0, B_nh1, A_mh1)
 
