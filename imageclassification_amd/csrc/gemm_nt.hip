@@ -357,7 +357,11 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
 //     overlap it, against the 25-30 us the shorter tail saves.  The vendor GEMM on these shapes (rocprofv3: Custom_Cijk_..._SK3_...
 //     MT256x256x64, 922-1060 TFLOP/s) is a Stream-K kernel: every CU walks an equal, contiguous share of ALL K iterations, so the
 //     same volume of partial tiles is exchanged all along the run, under other CUs' MFMAs -- a persistent form of this kernel,
-//     which round 3 measured 5 % slower than one workgroup per tile, would have to come first.
+//     which round 3 measured 5 % slower than one workgroup per tile, would have to come first.  (Round 5, same day: the plain persistent
+//     loop again -- tile loop around the whole body, thread index laundered per tile so that no lane constant is carried across
+//     the epilogue: 246 registers, no spill -- against one workgroup per tile in the same build on one box: K = 3072 259-268 vs
+//     273-278 us, N = 2304 206-217 vs 213-222, 768 x 768 and N = 3072 equal: not slower any more, not a gain by itself; and a
+//     Stream-K walk hands every CU two partial tiles, 134 MB of fp32 partials per launch against 80-160 MB of operands.)
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int PIECE = 16384, KTILE = 65536;   // bytes: one piece, one K tile (pieces in stream order A_mh0, B_nh0, B_nh1, A_mh1)
 
