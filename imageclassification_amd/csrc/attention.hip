@@ -77,11 +77,23 @@ __device__ __forceinline__ bf16x8 pack_acc2(const f32x4& lo, const f32x4& hi) { 
 // columns 8g..8g+7 (+32 for the second k-step)
 __device__ __forceinline__ void load_rowfrag(const bf16_t* __restrict__ base, long long ld, int row, int T, int g,
                                              bf16x8* f) {
-  const int rr = row < T ? row : 0;
-  const bf16_t* p = base + (long long)rr * ld + 8 * g;
+  // rows past T read the zero page: a select AFTER the loads (round 1-4: `if (row >= T) f = 0`) made every caller wait for the
+  // loads on the spot -- the "prefetch" of the next head's fragments at the top of a head was followed by s_waitcnt vmcnt(0)
+  // before the first MFMA (round 5, found in the ISA)
+  const bf16_t* p = row < T ? base + (long long)row * ld + 8 * g : (const bf16_t*)icamd_zero_page;
   f[0] = *(const bf16x8*)p;
-  f[1] = *(const bf16x8*)(p + 32);
-  if (row >= T) { f[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; f[1] = f[0]; }
+  f[1] = *(const bf16x8*)(p + (row < T ? 32 : 0));
+}
+
+// The same two loads issued behind hipcc's back (round 5): its s_waitcnt pass put vmcnt(3..0) in front of the first MFMAs of a head
+// for loads whose results are only read after the head (the next head's fragments) -- seen in the ISA of all three kernels,
+// whatever the source did about selects and stores.  The results must not be touched before prefetch_wait() has named them.
+__device__ __forceinline__ void load_rowfrag_async(const bf16_t* __restrict__ base, long long ld, int row, int T, int g,
+                                                   bf16x8* f) {
+  const bf16_t* p = row < T ? base + (long long)row * ld + 8 * g : (const bf16_t*)icamd_zero_page;
+  const bf16_t* p1 = p + (row < T ? 32 : 0);
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f[0]) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f[1]) : "v"(p1) : "memory");
 }
 
 // v_max3_f32 as is (fmaxf adds a canonicalising v_max per operand that comes out of an MFMA)
@@ -321,13 +333,14 @@ __global__ __launch_bounds__(PTHREADS, 4) void attn_bwd_dq_kernel(const bf16_t* 
       }
     } else {
       // the next head's fragments are requested now and used after the barrier
-      bf16x8 qn[2], don[2], on[2];
+      bf16x8 qn[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}}, don[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}}, on[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}};
       float lqn = 0.f;
       if (nxt < nheads) {
-        load_rowfrag(head_base(nxt), ld, qrow, T, g, qn);
-        load_rowfrag(dout + head_obase(nxt), ldo, qrow, T, g, don);
-        load_rowfrag(out + head_obase(nxt), ldo, qrow, T, g, on);
-        lqn = qrow < T ? lse[(long long)nxt * T + qrow] : 0.f;
+        load_rowfrag_async(head_base(nxt), ld, qrow, T, g, qn);
+        load_rowfrag_async(dout + head_obase(nxt), ldo, qrow, T, g, don);
+        load_rowfrag_async(out + head_obase(nxt), ldo, qrow, T, g, on);
+        const float* lp = qrow < T ? lse + ((long long)nxt * T + qrow) : (const float*)icamd_zero_page;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lqn) : "v"(lp) : "memory");
       }
       float dl = 0.f;
 #pragma unroll
@@ -381,6 +394,10 @@ __global__ __launch_bounds__(PTHREADS, 4) void attn_bwd_dq_kernel(const bf16_t* 
           *(u32x2*)(dst + db * 16 + 4 * g) = pk;
         }
       }
+      // Everything this wave has in flight retires HERE, in front of the hand-over barrier (round 5): with the output stores of this
+      // head still counted in vmcnt at the top of the next one, hipcc could not tell them from the fragment loads it issues there
+      // and put s_waitcnt vmcnt(0 / 1) in front of the first use of the CURRENT fragments -- the prefetch was waited for on the spot.
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(don[0]), "+v"(don[1]), "+v"(on[0]), "+v"(on[1]), "+v"(lqn) :: "memory");
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; dof[ks] = don[ks]; of[ks] = on[ks]; }
       lq = lqn;
@@ -424,6 +441,7 @@ __global__ __launch_bounds__(PTHREADS, 4) void attn_bwd_dkv_kernel(const bf16_t*
     load_rowfrag(head_base(hd) + (long long)H * HD, ld, krow, T, g, kf);
     load_rowfrag(head_base(hd) + 2ll * H * HD, ld, krow, T, g, vf);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first head's fragments are here before the loop (hipcc re-waited for them in it)
   __syncthreads();
   for (int it = 0; hd < nheads; hd += gridDim.x, ++it) {
     const int nxt = hd + gridDim.x;
@@ -440,10 +458,10 @@ __global__ __launch_bounds__(PTHREADS, 4) void attn_bwd_dkv_kernel(const bf16_t*
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     } else {
-      bf16x8 kn[2], vn[2];
+      bf16x8 kn[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}}, vn[2] = {bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0}};
       if (nxt < nheads) {
-        load_rowfrag(head_base(nxt) + (long long)H * HD, ld, krow, T, g, kn);
-        load_rowfrag(head_base(nxt) + 2ll * H * HD, ld, krow, T, g, vn);
+        load_rowfrag_async(head_base(nxt) + (long long)H * HD, ld, krow, T, g, kn);
+        load_rowfrag_async(head_base(nxt) + 2ll * H * HD, ld, krow, T, g, vn);
       }
       f32x4 dk[4], dv[4];
 #pragma unroll
@@ -494,6 +512,10 @@ __global__ __launch_bounds__(PTHREADS, 4) void attn_bwd_dkv_kernel(const bf16_t*
           *(u32x2*)(dstv + db * 16 + 4 * g) = pk;
         }
       }
+      // Everything this wave has in flight retires HERE, in front of the hand-over barrier (round 5): with the output stores of this
+      // head still counted in vmcnt at the top of the next one, hipcc could not tell them from the fragment loads it issues there
+      // and put s_waitcnt vmcnt(0 / 1) in front of the first use of the CURRENT fragments -- the prefetch was waited for on the spot.
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kn[0]), "+v"(kn[1]), "+v"(vn[0]), "+v"(vn[1]) :: "memory");
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
     }
