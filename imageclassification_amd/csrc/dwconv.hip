@@ -264,8 +264,10 @@ __global__ __launch_bounds__(256, 2) void dwconv7_rows_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
       const unsigned int off = ro + (unsigned)j * cb;
-      const unsigned int v = ld_stream((const unsigned int*)(xB + (off < last_off ? off : last_off)));
-      nxt[j] = ((colmask >> j) & 1u) ? v : 0u;
+      // columns outside the image read the zero page: a select AFTER the load (rounds 3-4) made hipcc wait for every load of the
+      // next row in front of this row's 49 multiply-adds -- the row was never "in flight under the arithmetic" (round 5, ISA)
+      const unsigned char* src = ((colmask >> j) & 1u) ? xB + (off < last_off ? off : last_off) : (const unsigned char*)icamd_zero_page;
+      nxt[j] = ld_stream((const unsigned int*)src);
     }
   };
   load_row(lo);
@@ -355,6 +357,7 @@ __device__ __forceinline__ void dw_wgrad_pass(const unsigned char* __restrict__ 
           f32x2 xu[13];
 #pragma unroll
           for (int j = 0; j < 13; ++j) {
+            // (the address-select form of the forward kernel's loads measured 2 % slower here at 56 x 56: 227.7 -> 232.5 us)
             const unsigned int raw = ((colmask >> j) & 1u) ? ld_stream((const unsigned int*)(xB + (ro + (unsigned)j * cb))) : 0u;
             xu[j] = f32x2{bf16_lo(raw), bf16_hi(raw)};
           }
