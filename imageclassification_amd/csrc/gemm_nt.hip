@@ -85,19 +85,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmNtParams& p, unsigned ch
     const int cgc = cg < p.N ? cg : 0;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + cgc);
+    // The eight addend vectors of this channel group are requested TOGETHER (round 5): as `if (addend && aoff >= 0) { load; use }`
+    // per row hipcc emitted branch -> global_load -> s_waitcnt vmcnt(0) -> ds_write thirty-two times in a row (seen in the ISA) --
+    // 32 dependent trips to memory per tile, ~7 us of a 26 us tile on the residual-add launches.  Rows without an addend (the
+    // even-grid form) read the zero page; so do their mask bytes.
+    u32x2 av[8];
+    unsigned int ab8[8];
+    if (p.addend != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16_t* src = aoff[i] >= 0 ? p.addend + aoff[i] + cgc : (const bf16_t*)icamd_zero_page;
+        av[i] = *(const u32x2*)src;
+        ab8[i] = 0xfu;
+      }
+      if (p.addend_bits != nullptr) {   // this lane's 4 channels are one nibble of the element's mask byte
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned char* bp = aoff[i] >= 0 ? p.addend_bits + ((aoff[i] + cgc) >> 3) : (const unsigned char*)icamd_zero_page;
+          ab8[i] = ((unsigned int)*bp >> (4 * (fq & 1))) & 0xfu;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int ml = wm * 128 + i * 16 + fr;
       f32x4 v = acc[j][i] + b4;
-      if (p.addend != nullptr && aoff[i] >= 0) {
-        const u32x2 a = *(const u32x2*)(p.addend + aoff[i] + cgc);
-        unsigned int ab = 0xfu;
-        if (p.addend_bits != nullptr)   // this lane's 4 channels are one nibble of the element's mask byte
-          ab = ((unsigned int)p.addend_bits[(aoff[i] + cgc) >> 3] >> (4 * (fq & 1))) & 0xfu;
-        v[0] += (ab & 1u) ? bf16_lo(a[0]) : 0.f;
-        v[1] += (ab & 2u) ? bf16_hi(a[0]) : 0.f;
-        v[2] += (ab & 4u) ? bf16_lo(a[1]) : 0.f;
-        v[3] += (ab & 8u) ? bf16_hi(a[1]) : 0.f;
+      if (p.addend != nullptr) {
+        v[0] += (ab8[i] & 1u) ? bf16_lo(av[i][0]) : 0.f;
+        v[1] += (ab8[i] & 2u) ? bf16_hi(av[i][0]) : 0.f;
+        v[2] += (ab8[i] & 4u) ? bf16_lo(av[i][1]) : 0.f;
+        v[3] += (ab8[i] & 8u) ? bf16_hi(av[i][1]) : 0.f;
       }
       if (p.relu) {
 #pragma unroll
