@@ -1,5 +1,9 @@
 #!/bin/bash
-# same-box A/B of builds of the library (tools/attn_ab/lib_*.so): args = variant names
+# Same-box A/B of builds of the library: args = variant names.  Prepare (build container) tools/attn_ab/lib_<name>.so, e.g.
+#   bash imageclassification_amd/csrc/build.sh && cp imageclassification_amd/csrc/libicamd.so tools/attn_ab/lib_new.so
+#   git stash; bash imageclassification_amd/csrc/build.sh; cp imageclassification_amd/csrc/libicamd.so tools/attn_ab/lib_old.so; git stash pop
+# (tools/attn_ab/ is git-ignored but travels to the GPU box), then: gpurun -- 'bash tools/r5_lib_ab.sh old new'.
+# The body below is the last comparison of the round (depthwise weight gradient); edit the bench lines for another one.
 L=imageclassification_amd/csrc/libicamd.so
 cp $L /tmp/lib_keep.so
 for v in "$@"; do cp tools/attn_ab/lib_$v.so $L; echo "$v"; python3 tools/bench_dwconv.py 2>&1 | grep -v amdgpu.ids; done
