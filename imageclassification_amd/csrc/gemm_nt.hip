@@ -377,7 +377,8 @@ __global__ __launch_bounds__(TN * 2, 2) void gemm_nt_kernel(const GemmNtParams p
 //     which round 3 measured 5 % slower than one workgroup per tile, would have to come first.  (Round 5, same day: the plain persistent
 //     loop again -- tile loop around the whole body, thread index laundered per tile so that no lane constant is carried across
 //     the epilogue: 246 registers, no spill -- against one workgroup per tile in the same build on one box: K = 3072 259-268 vs
-//     273-278 us, N = 2304 206-217 vs 213-222, 768 x 768 and N = 3072 equal: not slower any more, not a gain by itself; and a
+//     273-278 us, N = 2304 206-217 vs 213-222, 768 x 768 and N = 3072 equal; against THIS kernel (231 registers) in the ViT-B/16 step,
+//     three rounds on one box: 35.59-35.69 ms both ways -- not slower any more, not a gain by itself; and a
 //     Stream-K walk hands every CU two partial tiles, 134 MB of fp32 partials per launch against 80-160 MB of operands.)
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int PIECE = 16384, KTILE = 65536;   // bytes: one piece, one K tile (pieces in stream order A_mh0, B_nh0, B_nh1, A_mh1)
